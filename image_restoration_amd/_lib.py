@@ -1,0 +1,122 @@
+"""ctypes binding of the C-ABI declared in ``include/mi_restore.h``.
+
+The library is loaded lazily on first use and the load fails loudly: there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi_restore.so")
+
+MI_F32, MI_BF16 = 0, 1
+c_i64 = C.c_int64
+vp = C.c_void_p
+fp = C.c_void_p  # float* passed as raw addresses
+
+
+class PwDesc(C.Structure):
+    _fields_ = [("x1", vp), ("x1_bs", c_i64), ("x1_gs", c_i64), ("k1", C.c_int),
+                ("x2", vp), ("x2_bs", c_i64), ("x2_gs", c_i64), ("k2", C.c_int),
+                ("w", fp), ("w_bs", c_i64), ("w_gs", c_i64), ("w_sm", c_i64), ("w_sk", c_i64),
+                ("bias", fp), ("bias_gs", c_i64),
+                ("r", vp), ("r_bs", c_i64), ("r_gs", c_i64),
+                ("y", vp), ("y_bs", c_i64), ("y_gs", c_i64),
+                ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int)]
+
+
+class GramDesc(C.Structure):
+    _fields_ = [("a", vp), ("a_bs", c_i64), ("a_gs", c_i64), ("ma", C.c_int),
+                ("b", vp), ("b_bs", c_i64), ("b_gs", c_i64), ("mb", C.c_int),
+                ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int),
+                ("sum_batch", C.c_int), ("accumulate", C.c_int),
+                ("out", fp), ("out_ld", c_i64), ("out_zs", c_i64), ("sumsq", fp)]
+
+
+class MdtaShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("heads", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("dtype", C.c_int), ("ks", C.c_int)]
+
+
+class MdtaParams(C.Structure):
+    _fields_ = [("temperature", fp), ("qkv_w", fp), ("qkv_b", fp), ("dw_w", fp), ("dw_b", fp),
+                ("proj_w", fp), ("proj_b", fp)]
+
+
+class MdtaGrads(C.Structure):
+    _fields_ = [("temperature", fp), ("qkv_w", fp), ("qkv_b", fp), ("dw_w", fp), ("dw_b", fp),
+                ("proj_w", fp), ("proj_b", fp), ("accumulate", C.c_int)]
+
+
+class GdfnShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("dtype", C.c_int), ("ks", C.c_int)]
+
+
+class GdfnParams(C.Structure):
+    _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp)]
+
+
+class GdfnGrads(C.Structure):
+    _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp),
+                ("accumulate", C.c_int)]
+
+
+# symbol -> (restype, argtypes); this table is also what tests/test_cabi.py checks against the header
+SIGNATURES = {
+    "mi_version": (C.c_int, []),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_ln_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "mi_ln_bwd_workspace": (C.c_size_t, [C.c_int, C.c_int, c_i64]),
+    "mi_ln_bwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,
+                            vp, vp]),
+    "mi_dwconv_fwd": (C.c_int, [vp, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_dwconv_gate_fwd": (C.c_int, [vp, fp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_dwconv_bwd_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_dwconv_bwd": (C.c_int, [vp, vp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                vp, vp]),
+    "mi_dwconv_gate_bwd": (C.c_int, [vp, vp, vp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, vp, vp]),
+    "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp]),
+    "mi_gram_workspace": (C.c_size_t, [C.POINTER(GramDesc)]),
+    "mi_gram": (C.c_int, [C.POINTER(GramDesc), vp, vp]),
+    "mi_mdta_saved_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),
+    "mi_mdta_workspace": (C.c_size_t, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fwd": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), vp, vp, vp, vp, vp, vp]),
+    "mi_mdta_bwd": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), vp, vp, vp, C.POINTER(MdtaGrads), vp, vp,
+                              vp]),
+    "mi_gdfn_saved_bytes": (C.c_size_t, [C.POINTER(GdfnShape)]),
+    "mi_gdfn_workspace": (C.c_size_t, [C.POINTER(GdfnShape)]),
+    "mi_gdfn_fwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, vp, vp, vp]),
+    "mi_gdfn_bwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, C.POINTER(GdfnGrads), vp, vp,
+                              vp]),
+    "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                C.c_float, vp]),
+    "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),
+    "mi_l1_loss": (C.c_int, [vp, vp, vp, fp, c_i64, C.c_float, C.c_int, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises RuntimeError (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"mi_restore {what} failed (rc={rc}): {msg}")

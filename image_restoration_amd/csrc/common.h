@@ -1,0 +1,176 @@
+// Shared device/host helpers for the gfx950 Restormer-block kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi_restore.h"
+
+namespace mi {
+
+typedef __bf16 bf16;
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define MI_CHECK_ARG(cond, ...)                \
+  do {                                         \
+    if (!(cond)) {                             \
+      mi::set_error(__VA_ARGS__);              \
+      return MI_ERR_ARG;                       \
+    }                                          \
+  } while (0)
+#define MI_CHECK_HIP(expr)                                                          \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      mi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MI_ERR_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+#define MI_LAUNCH_CHECK() MI_CHECK_HIP(hipGetLastError())
+#define MI_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != MI_OK) return rc_; \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t dtype_size(int dt) { return dt == MI_BF16 ? 2 : 4; }
+
+// Bump allocator over a caller-provided blob (saved-for-backward / workspace carving).
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+  template <typename U = void>
+  U* take(size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return base ? reinterpret_cast<U*>(base + o) : nullptr;
+  }
+};
+
+// ---- device helpers ---------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int bits16) { return __uint_as_float(bits16 << 16); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float from(float v) { return v; }
+};
+template <> struct Cvt<bf16> {
+  static __device__ __forceinline__ bf16 from(float v) { return (bf16)v; }  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+};
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = Cvt<T>::from(v); }
+
+// Vector access of V consecutive elements (V*sizeof(T) in {4,8,16} bytes, pointer aligned to it).
+template <typename T, int V> struct Vec;
+template <> struct Vec<float, 1> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) { o[0] = p[0]; }
+  static __device__ __forceinline__ void st(float* p, const float* v) { p[0] = v[0]; }
+};
+template <> struct Vec<float, 2> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    f32x2 t = *reinterpret_cast<const f32x2*>(p); o[0] = t[0]; o[1] = t[1];
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) {
+    f32x2 t = {v[0], v[1]}; *reinterpret_cast<f32x2*>(p) = t;
+  }
+};
+template <> struct Vec<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Vec<bf16, 1> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) { o[0] = (float)p[0]; }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) { p[0] = (bf16)v[0]; }
+};
+template <> struct Vec<bf16, 2> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) {
+    unsigned int t = *reinterpret_cast<const unsigned int*>(p);
+    o[0] = bf16_bits_to_f32(t & 0xffffu); o[1] = bf16_bits_to_f32(t >> 16);
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) {
+    bf16 a = (bf16)v[0], b = (bf16)v[1];
+    unsigned int t = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
+    *reinterpret_cast<unsigned int*>(p) = t;
+  }
+};
+template <> struct Vec<bf16, 4> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) {
+    u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    o[0] = bf16_bits_to_f32(t[0] & 0xffffu); o[1] = bf16_bits_to_f32(t[0] >> 16);
+    o[2] = bf16_bits_to_f32(t[1] & 0xffffu); o[3] = bf16_bits_to_f32(t[1] >> 16);
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) {
+    u32x2 t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16 a = (bf16)v[2 * i], b = (bf16)v[2 * i + 1];
+      t[i] = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
+    }
+    *reinterpret_cast<u32x2*>(p) = t;
+  }
+};
+template <> struct Vec<bf16, 8> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* o) {
+    u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); o[2 * i + 1] = bf16_bits_to_f32(t[i] >> 16); }
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16 a = (bf16)v[2 * i], b = (bf16)v[2 * i + 1];
+      t[i] = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
+    }
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (Restormer.py:91: F.gelu default = erf form)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+#endif  // __HIPCC__
+
+// generic small kernels implemented in util.hip, used by several modules
+int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld,
+                       int accumulate, float scale, hipStream_t st);
+
+}  // namespace mi

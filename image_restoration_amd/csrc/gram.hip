@@ -1,0 +1,274 @@
+// Row-Gram contraction over the pixel axis:  G[z][i][j] = sum_n A[z][i][n] * Bm[z][j][n].
+// This one kernel is MDTA's q k^T (Restormer.py:124, with the F.normalize row sums of squares of
+// :121-122 taken from the same operand fragments), the per-image dY V^T of its backward, and every
+// 1x1-conv weight gradient (sum over batch).  Both operands are pixel-contiguous, so both MFMA
+// fragments are plain 16-byte row reads from LDS.  The pixel axis is split across workgroups; partial
+// tiles go to a workspace and are summed in a fixed order by a second kernel (bitwise reproducible).
+#include <type_traits>
+
+#include "common.h"
+
+namespace mi {
+
+struct GramK {
+  const void* a; int64_t a_bs, a_gs; int ma;
+  const void* b; int64_t b_bs, b_gs; int mb;
+  int64_t n; int groups; int Z;
+  float* part;     // [splits][Z][ma][mb]
+  float* ss_part;  // [splits][Z][ma+mb] or null
+  int chunks_per_split, nchunks, tiles_b, vec_ok;
+};
+
+template <typename T, int F, bool SS>
+__global__ __launch_bounds__(256) void gram_kernel(GramK p) {
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int TA = 32 * F;               // tile rows (A) == tile cols (B)
+  constexpr int KC = F32 ? 32 : 64;        // pixels per staged chunk (128 bytes per row)
+  constexpr int AS = F32 ? 34 : 72;        // LDS row stride, elements
+  constexpr int EPV = F32 ? 4 : 8;         // elements per 16-byte vector
+  __shared__ __attribute__((aligned(16))) T As[TA * AS];
+  __shared__ __attribute__((aligned(16))) T Bs[TA * AS];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
+  const int i0 = ta * TA, j0 = tb * TA;
+  const T* A = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
+  const T* B = (const T*)p.b + zb * p.b_bs + zg * p.b_gs;
+  const int c_begin = blockIdx.x * p.chunks_per_split;
+  int c_end = c_begin + p.chunks_per_split;
+  if (c_end > p.nchunks) c_end = p.nchunks;
+
+  u32x4 areg[F], breg[F];
+  auto load_rows = [&](const T* base, int row0, int rows, int chunk, u32x4* regs) {
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      const int v = t + 256 * i;
+      const int row = v >> 3, seg = v & 7;
+      const int64_t n = (int64_t)chunk * KC + seg * EPV;
+      const int r = row0 + row;
+      if (r < rows && p.vec_ok && n < p.n) {
+        regs[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)r * p.n + n);
+      } else {
+        __attribute__((aligned(16))) T tmp[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) tmp[e] = (r < rows && n + e < p.n) ? base[(int64_t)r * p.n + n + e] : Cvt<T>::from(0.f);
+        regs[i] = *reinterpret_cast<u32x4*>(tmp);
+      }
+    }
+  };
+  auto write_rows = [&](T* dst, const u32x4* regs) {
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      const int v = t + 256 * i;
+      const int row = v >> 3, seg = v & 7;
+      T* d = dst + row * AS + seg * EPV;
+      if constexpr (F32) {  // 136-byte rows: 8-byte aligned only
+        *reinterpret_cast<u32x2*>(d) = (u32x2){regs[i][0], regs[i][1]};
+        *reinterpret_cast<u32x2*>(d + 2) = (u32x2){regs[i][2], regs[i][3]};
+      } else {
+        *reinterpret_cast<u32x4*>(d) = regs[i];
+      }
+    }
+  };
+
+  f32x4 acc[F][F];
+  float ssa[F], ssb[F];
+#pragma unroll
+  for (int a = 0; a < F; ++a) {
+    ssa[a] = 0.f; ssb[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < F; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int ra = wr * 16 * F, cb = wc * 16 * F;  // wave's first row / col inside the tile
+
+  if (c_begin < c_end) {
+    load_rows(A, i0, p.ma, c_begin, areg);
+    load_rows(B, j0, p.mb, c_begin, breg);
+  }
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();
+    write_rows(As, areg);
+    write_rows(Bs, breg);
+    __syncthreads();
+    if (c + 1 < c_end) {
+      load_rows(A, i0, p.ma, c + 1, areg);
+      load_rows(B, j0, p.mb, c + 1, breg);
+    }
+    if constexpr (F32) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int kk = 4 * ks + g;
+        float av[F], bv[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          av[f] = As[(ra + 16 * f + li) * AS + kk];
+          bv[f] = Bs[(cb + 16 * f + li) * AS + kk];
+          if (SS) { ssa[f] += av[f] * av[f]; ssb[f] += bv[f] * bv[f]; }
+        }
+#pragma unroll
+        for (int fa = 0; fa < F; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < F; ++fb)
+            acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KC / 32; ++ks) {
+        s16x8 av[F], bv[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          av[f] = *reinterpret_cast<const s16x8*>(&As[(ra + 16 * f + li) * AS + 32 * ks + 8 * g]);
+          bv[f] = *reinterpret_cast<const s16x8*>(&Bs[(cb + 16 * f + li) * AS + 32 * ks + 8 * g]);
+          if (SS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = bf16_bits_to_f32((unsigned int)(unsigned short)av[f][e]);
+              const float y = bf16_bits_to_f32((unsigned int)(unsigned short)bv[f][e]);
+              ssa[f] += x * x; ssb[f] += y * y;
+            }
+          }
+        }
+#pragma unroll
+        for (int fa = 0; fa < F; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < F; ++fb)
+            acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
+      }
+    }
+  }
+
+  // lane holds G[i0+ra+16fa+4g+r][j0+cb+16fb+li]
+  float* pz = p.part + ((int64_t)blockIdx.x * p.Z + z) * ((int64_t)p.ma * p.mb);
+#pragma unroll
+  for (int fa = 0; fa < F; ++fa)
+#pragma unroll
+    for (int fb = 0; fb < F; ++fb) {
+      const int j = j0 + cb + 16 * fb + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ra + 16 * fa + 4 * g + r;
+        if (i < p.ma && j < p.mb) pz[(int64_t)i * p.mb + j] = acc[fa][fb][r];
+      }
+    }
+  if (SS && p.ss_part) {
+    float* sz = p.ss_part + ((int64_t)blockIdx.x * p.Z + z) * (p.ma + p.mb);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float sa = ssa[f], sb = ssb[f];
+      sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      if (g == 0) {
+        const int i = i0 + ra + 16 * f + li, j = j0 + cb + 16 * f + li;
+        if (wc == 0 && tb == 0 && i < p.ma) sz[i] = sa;
+        if (wr == 0 && ta == 0 && j < p.mb) sz[p.ma + j] = sb;
+      }
+    }
+  }
+}
+
+// out[zo][i*ld + j] (+)= sum_{split} sum_{b if sum_batch} part[split][b*groups+g][i][j]
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int splits, int batch, int groups, int ma, int mb, int64_t out_ld,
+                                                          int64_t out_zs, int sum_batch, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)ma * mb;
+  if (e >= per) return;
+  const int zo = blockIdx.y;
+  const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
+  const int Z = batch * groups;
+  float s = 0.f;
+  if (sum_batch) {
+    for (int sp = 0; sp < splits; ++sp)
+      for (int b = 0; b < batch; ++b) s += part[((int64_t)sp * Z + (int64_t)b * groups + zo) * per + e];
+  } else {
+    for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * Z + zo) * per + e];
+  }
+  float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
+  *o = (accumulate ? *o : 0.f) + s;
+}
+
+struct GramPlan { int F, kc, nchunks, tiles_a, tiles_b, splits, cps, Z; size_t part_bytes, ss_bytes; };
+
+static GramPlan gram_plan(const mi_gram_desc* d) {
+  GramPlan g;
+  g.F = (d->ma > 64 || d->mb > 64) ? 4 : 2;
+  const int tile = 32 * g.F;
+  g.kc = d->dtype == MI_BF16 ? 64 : 32;
+  g.nchunks = cdiv(d->n, g.kc);
+  g.tiles_a = cdiv(d->ma, tile);
+  g.tiles_b = cdiv(d->mb, tile);
+  g.Z = d->batch * d->groups;
+  const int64_t tiles = (int64_t)g.tiles_a * g.tiles_b * g.Z;
+  int64_t want = 1024 / (tiles > 0 ? tiles : 1);
+  if (want < 1) want = 1;
+  if (want > g.nchunks) want = g.nchunks;
+  g.cps = cdiv(g.nchunks, want);
+  g.splits = cdiv(g.nchunks, g.cps);
+  g.part_bytes = align_up((size_t)g.splits * g.Z * d->ma * d->mb * sizeof(float), 256);
+  g.ss_bytes = d->sumsq ? align_up((size_t)g.splits * g.Z * (d->ma + d->mb) * sizeof(float), 256) : 0;
+  return g;
+}
+
+static int gram_check(const mi_gram_desc* d) {
+  MI_CHECK_ARG(d && d->a && d->b && d->out, "gram: null pointer");
+  MI_CHECK_ARG(d->ma > 0 && d->mb > 0 && d->n > 0 && d->batch > 0 && d->groups > 0, "gram: bad shape");
+  MI_CHECK_ARG(d->dtype == MI_F32 || d->dtype == MI_BF16, "gram: bad dtype %d", d->dtype);
+  MI_CHECK_ARG(d->out_ld >= d->mb, "gram: out_ld < mb");
+  MI_CHECK_ARG(!(d->sumsq && d->sum_batch), "gram: sumsq with sum_batch is not supported");
+  return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" size_t mi_gram_workspace(const mi_gram_desc* d) {
+  if (!d || d->ma <= 0 || d->mb <= 0 || d->n <= 0 || d->batch <= 0 || d->groups <= 0) return 0;
+  GramPlan g = gram_plan(d);
+  // sumsq presence may differ between the sizing call and the real call: always reserve it
+  const size_t ss = align_up((size_t)g.splits * g.Z * (d->ma + d->mb) * sizeof(float), 256);
+  return g.part_bytes + ss;
+}
+
+extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
+  MI_TRY(gram_check(d));
+  MI_CHECK_ARG(ws, "gram: null workspace");
+  GramPlan g = gram_plan(d);
+  hipStream_t st = (hipStream_t)stream;
+  GramK k;
+  k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
+  k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
+  k.n = d->n; k.groups = d->groups; k.Z = g.Z;
+  k.part = (float*)ws;
+  k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
+  k.chunks_per_split = g.cps; k.nchunks = g.nchunks; k.tiles_b = g.tiles_b;
+  const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
+  bool ok = (d->n % vec == 0) && aligned16(d->a) && aligned16(d->b);
+  ok = ok && d->a_bs % vec == 0 && d->a_gs % vec == 0 && d->b_bs % vec == 0 && d->b_gs % vec == 0;
+  k.vec_ok = ok ? 1 : 0;
+  dim3 grid(g.splits, g.tiles_a * g.tiles_b, g.Z), block(256);
+  MI_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gram: grid too large");
+  const bool ss = d->sumsq != nullptr;
+#define GRAM_CASE(T, F)                                                                     \
+  do {                                                                                      \
+    if (ss) hipLaunchKernelGGL((gram_kernel<T, F, true>), grid, block, 0, st, k);           \
+    else hipLaunchKernelGGL((gram_kernel<T, F, false>), grid, block, 0, st, k);             \
+  } while (0)
+  if (d->dtype == MI_F32) { if (g.F == 4) GRAM_CASE(float, 4); else GRAM_CASE(float, 2); }
+  else { if (g.F == 4) GRAM_CASE(bf16, 4); else GRAM_CASE(bf16, 2); }
+#undef GRAM_CASE
+  MI_LAUNCH_CHECK();
+  const int zo = d->sum_batch ? d->groups : g.Z;
+  const int64_t per = (int64_t)d->ma * d->mb;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 256), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
+                     d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+  MI_LAUNCH_CHECK();
+  if (ss) {
+    const int64_t cols = (int64_t)g.Z * (d->ma + d->mb);
+    MI_TRY(launch_reduce_rows(k.ss_part, d->sumsq, g.splits, cols, cols, 0, 1.0f, st));
+  }
+  return MI_OK;
+}

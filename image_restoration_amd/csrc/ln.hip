@@ -1,0 +1,319 @@
+// Channel LayerNorm on NCHW planes (Restormer.py:25-70): the reduction runs over C with
+// stride N = H*W, so lanes map to consecutive pixels (coalesced) and the 8 waves of a
+// workgroup split the channels; per-pixel partial sums cross waves through LDS.
+// HBM-bound: reads x once (held in registers for the two-pass variance), writes y once.
+#include "common.h"
+
+namespace mi {
+
+constexpr int LN_WAVES = 8;
+constexpr float LN_EPS = 1e-5f;
+
+template <typename T, int CPT, int VEC, bool WITH_BIAS>
+__global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, T* __restrict__ y,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                int C, int64_t N) {
+  constexpr int TILE = 64 * VEC;
+  __shared__ float red[LN_WAVES][TILE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * TILE + lane * VEC;
+  const bool valid = n < N;  // VEC>1 is only used when N % VEC == 0
+  const int64_t boff = (int64_t)blockIdx.y * C * N;
+  const T* xb = x + boff;
+  T* yb = y + boff;
+
+  float v[CPT][VEC];
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = wv + LN_WAVES * i;
+    if (c < C && valid) {
+      Vec<T, VEC>::ld(xb + (int64_t)c * N + n, v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] += v[i][j];
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[wv][lane * VEC + j] = s[j];
+  __syncthreads();
+  float mu[VEC], rs[VEC];
+  const float invC = 1.0f / (float)C;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_WAVES; ++k) t += red[k][lane * VEC + j];
+    mu[j] = t * invC;
+    s[j] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = wv + LN_WAVES * i;
+    if (c < C) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { float d = v[i][j] - mu[j]; s[j] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[wv][lane * VEC + j] = s[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_WAVES; ++k) t += red[k][lane * VEC + j];
+    rs[j] = 1.0f / sqrtf(t * invC + LN_EPS);
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = wv + LN_WAVES * i;
+    if (c < C) {
+      const float wc = w[c];
+      const float bc = WITH_BIAS ? b[c] : 0.f;
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        o[j] = WITH_BIAS ? (v[i][j] - mu[j]) * rs[j] * wc + bc : v[i][j] * rs[j] * wc;
+      Vec<T, VEC>::st(yb + (int64_t)c * N + n, o);
+    }
+  }
+  if (wv == 0 && mean_out) {
+    const int64_t so = (int64_t)blockIdx.y * N + n;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mean_out[so + j] = mu[j]; rstd_out[so + j] = rs[j]; }
+  }
+}
+
+// Backward.  WithBias:  xh=(x-mu)r, g=dy*w, dx = r*(g - mean_c(g) - xh*mean_c(g*xh)), dw+=dy*xh, db+=dy.
+// BiasFree (y = x*r*w): g=dy*w, dx = r*g - r^3*(x-mu)*mean_c(g*x), dw += dy*x*r.
+template <typename T, int CPT, int VEC, bool WITH_BIAS>
+__global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const float* __restrict__ w, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                                T* __restrict__ dx, float* __restrict__ part, int C, int64_t N,
+                                                                int tiles_per_block, int tiles_per_image) {
+  constexpr int TILE = 64 * VEC;
+  __shared__ float red1[LN_WAVES][TILE];
+  __shared__ float red2[LN_WAVES][TILE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t boff = (int64_t)blockIdx.y * C * N;
+  const float invC = 1.0f / (float)C;
+  float aw[CPT], ab[CPT], wreg[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    aw[i] = 0.f; ab[i] = 0.f;
+    const int c = wv + LN_WAVES * i;
+    wreg[i] = c < C ? w[c] : 0.f;
+  }
+  const int t0 = blockIdx.x * tiles_per_block;
+  for (int t = t0; t < t0 + tiles_per_block && t < tiles_per_image; ++t) {
+    const int64_t n = (int64_t)t * TILE + lane * VEC;
+    const bool valid = n < N;
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mu[j] = valid ? mean[(int64_t)blockIdx.y * N + n + j] : 0.f;
+      rs[j] = valid ? rstd[(int64_t)blockIdx.y * N + n + j] : 0.f;
+    }
+    float g[CPT][VEC], xv[CPT][VEC];
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = wv + LN_WAVES * i;
+      if (c < C && valid) {
+        Vec<T, VEC>::ld(dy + boff + (int64_t)c * N + n, g[i]);
+        Vec<T, VEC>::ld(x + boff + (int64_t)c * N + n, xv[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { g[i][j] = 0.f; xv[i][j] = 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float dyv = g[i][j];
+        if (WITH_BIAS) {
+          const float xh = (xv[i][j] - mu[j]) * rs[j];
+          aw[i] += dyv * xh; ab[i] += dyv;
+          const float gw = dyv * wreg[i];
+          s1[j] += gw; s2[j] += gw * xh;
+          g[i][j] = gw; xv[i][j] = xh;
+        } else {
+          aw[i] += dyv * xv[i][j] * rs[j];
+          const float gw = dyv * wreg[i];
+          s2[j] += gw * xv[i][j];
+          g[i][j] = gw; xv[i][j] = xv[i][j] - mu[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red1[wv][lane * VEC + j] = s1[j]; red2[wv][lane * VEC + j] = s2[j]; }
+    __syncthreads();
+    float m1[VEC], m2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float a = 0.f, bsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < LN_WAVES; ++k) { a += red1[k][lane * VEC + j]; bsum += red2[k][lane * VEC + j]; }
+      m1[j] = a * invC; m2[j] = bsum * invC;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = wv + LN_WAVES * i;
+        if (c < C) {
+          float o[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if (WITH_BIAS) o[j] = rs[j] * (g[i][j] - m1[j] - xv[i][j] * m2[j]);
+            else o[j] = rs[j] * g[i][j] - rs[j] * rs[j] * rs[j] * xv[i][j] * m2[j];
+          }
+          if (dres) {
+            float r[VEC];
+            Vec<T, VEC>::ld(dres + boff + (int64_t)c * N + n, r);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] += r[j];
+          }
+          Vec<T, VEC>::st(dx + boff + (int64_t)c * N + n, o);
+        }
+      }
+    }
+  }
+  // every channel is owned by exactly one wave: reduce over its 64 lanes, lane 0 writes the block partial
+  float* prow = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C);
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = wv + LN_WAVES * i;
+    const float sw = wave_sum(aw[i]);
+    const float sb = wave_sum(ab[i]);
+    if (lane == 0 && c < C) { prow[c] = sw; prow[C + c] = sb; }
+  }
+}
+
+static void ln_bwd_grid(int B, int64_t N, int vec, int* tiles_img, int* tpb, int* gx) {
+  const int tile = 64 * vec;
+  *tiles_img = cdiv(N, tile);
+  int want = cdiv((int64_t)*tiles_img * B, 1024);
+  if (want < 1) want = 1;
+  *tpb = want;
+  *gx = cdiv(*tiles_img, *tpb);
+}
+
+template <typename T, int VEC, bool WB>
+static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, float* mean, float* rstd, int B, int C,
+                           int64_t N, hipStream_t st) {
+  dim3 grid(cdiv(N, 64 * VEC), B), block(64 * LN_WAVES);
+#define LN_FWD_CASE(CPT)                                                                                   \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, x, w, b, y, mean, rstd, C, N)
+  if (C <= 16) LN_FWD_CASE(2);
+  else if (C <= 48) LN_FWD_CASE(6);
+  else if (C <= 96) LN_FWD_CASE(12);
+  else if (C <= 192) LN_FWD_CASE(24);
+  else if (C <= 384) LN_FWD_CASE(48);
+  else { set_error("ln_fwd: C=%d > 384 unsupported", C); return MI_ERR_ARG; }
+#undef LN_FWD_CASE
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+template <typename T, int VEC, bool WB>
+static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float* mean, const float* rstd, const T* dres,
+                           T* dx, float* part, int B, int C, int64_t N, int gx, int tpb, int tiles_img, hipStream_t st) {
+  dim3 grid(gx, B), block(64 * LN_WAVES);
+#define LN_BWD_CASE(CPT)                                                                                     \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, dy, x, w, mean, rstd, dres, dx, part, C, N, \
+                     tpb, tiles_img)
+  if (C <= 16) LN_BWD_CASE(2);
+  else if (C <= 48) LN_BWD_CASE(6);
+  else if (C <= 96) LN_BWD_CASE(12);
+  else if (C <= 192) LN_BWD_CASE(24);
+  else if (C <= 384) LN_BWD_CASE(48);
+  else { set_error("ln_bwd: C=%d > 384 unsupported", C); return MI_ERR_ARG; }
+#undef LN_BWD_CASE
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+static int ln_vec(int dtype, int64_t N, const void* a, const void* b) {
+  if (dtype != MI_BF16) return 1;
+  const bool ok = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3u) == 0;
+  return ok ? 2 : 1;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_ln_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int B, int C,
+                         int64_t N, int with_bias, int dtype, void* stream) {
+  MI_CHECK_ARG(x && w && y, "ln_fwd: null pointer");
+  MI_CHECK_ARG(B > 0 && C > 0 && N > 0, "ln_fwd: bad shape B=%d C=%d N=%lld", B, C, (long long)N);
+  MI_CHECK_ARG(!with_bias || b, "ln_fwd: with_bias needs b");
+  MI_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or both NULL");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_fwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32) {
+    return with_bias ? ln_fwd_dispatch<float, 1, true>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st)
+                     : ln_fwd_dispatch<float, 1, false>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st);
+  }
+  if (ln_vec(dtype, N, x, y) == 2) {
+    return with_bias ? ln_fwd_dispatch<bf16, 2, true>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st)
+                     : ln_fwd_dispatch<bf16, 2, false>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st);
+  }
+  return with_bias ? ln_fwd_dispatch<bf16, 1, true>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st)
+                   : ln_fwd_dispatch<bf16, 1, false>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st);
+}
+
+extern "C" size_t mi_ln_bwd_workspace(int B, int C, int64_t N) {
+  int tiles_img, tpb, gx1, gx2;
+  ln_bwd_grid(B, N, 1, &tiles_img, &tpb, &gx1);
+  ln_bwd_grid(B, N, 2, &tiles_img, &tpb, &gx2);
+  const int gx = gx1 > gx2 ? gx1 : gx2;
+  return align_up((size_t)gx * B * 2 * C * sizeof(float), 256);
+}
+
+extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dw, float* db, int B, int C, int64_t N, int with_bias,
+                         int accumulate, int dtype, void* ws, void* stream) {
+  MI_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && ws, "ln_bwd: null pointer");
+  MI_CHECK_ARG(B > 0 && C > 0 && N > 0, "ln_bwd: bad shape");
+  MI_CHECK_ARG(!with_bias || db, "ln_bwd: with_bias needs db");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  int vec = ln_vec(dtype, N, dy, x);
+  if (vec == 2 && ln_vec(dtype, N, dx, dres) != 2) vec = 1;
+  int tiles_img, tpb, gx;
+  ln_bwd_grid(B, N, vec, &tiles_img, &tpb, &gx);
+  float* part = (float*)ws;
+  int rc;
+  if (dtype == MI_F32) {
+    rc = with_bias ? ln_bwd_dispatch<float, 1, true>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
+                                                     (float*)dx, part, B, C, N, gx, tpb, tiles_img, st)
+                   : ln_bwd_dispatch<float, 1, false>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
+                                                      (float*)dx, part, B, C, N, gx, tpb, tiles_img, st);
+  } else if (vec == 2) {
+    rc = with_bias ? ln_bwd_dispatch<bf16, 2, true>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                    (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st)
+                   : ln_bwd_dispatch<bf16, 2, false>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                     (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st);
+  } else {
+    rc = with_bias ? ln_bwd_dispatch<bf16, 1, true>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                    (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st)
+                   : ln_bwd_dispatch<bf16, 1, false>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                     (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st);
+  }
+  if (rc != MI_OK) return rc;
+  const int64_t rows = (int64_t)gx * B;
+  MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st));
+  if (with_bias) MI_TRY(launch_reduce_rows(part + C, db, rows, C, 2 * C, accumulate, 1.0f, st));
+  return MI_OK;
+}

@@ -1,0 +1,158 @@
+// Small shared kernels: deterministic row reduction, AdamW on flat buffers, casts, L1 loss.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace mi {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// out[c] = (accumulate ? out[c] : 0) + scale * sum_r part[r*ld + c].  One thread per column chunk,
+// rows walked in a fixed order -> bitwise reproducible.  256 threads = 64 columns x 4 row-phases.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int64_t rows, int64_t cols, int64_t ld, int accumulate,
+                                                          float scale) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = ph; r < rows; r += 4) acc += part[r * ld + c];
+  sm[ph][cx] = acc;
+  __syncthreads();
+  if (ph == 0 && c < cols) {
+    const float t = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
+    out[c] = (accumulate ? out[c] : 0.f) + scale * t;
+  }
+}
+
+int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate,
+                       float scale, hipStream_t st) {
+  if (cols <= 0) return MI_OK;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, part, out, rows, cols, part_ld,
+                     accumulate, scale);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+// AdamW, torch semantics (decoupled weight decay, bias-corrected moments).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float gscale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = gv[j] * gscale;
+        pv[j] *= 1.0f - lr * wd;
+        mv[j] = b1 * mv[j] + (1.0f - b1) * gr;
+        vv[j] = b2 * vv[j] + (1.0f - b2) * gr * gr;
+        const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+        pv[j] -= (lr / bc1) * (mv[j] / denom);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv;
+      *reinterpret_cast<f32x4*>(m + i) = mv;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        const float gr = g[k] * gscale;
+        float pv = p[k] * (1.0f - lr * wd);
+        const float mv = b1 * m[k] + (1.0f - b1) * gr;
+        const float vv = b2 * v[k] + (1.0f - b2) * gr * gr;
+        pv -= (lr / bc1) * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+        p[k] = pv; m[k] = mv; v[k] = vv;
+      }
+    }
+  }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = Cvt<D>::from(to_f32(s[i]));
+}
+
+// per-block partial of sum|a-b| into part[blockIdx.x]; da = sign(a-b)*scale
+template <typename T>
+__global__ __launch_bounds__(256) void l1_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ da,
+                                                 float* __restrict__ part, int64_t n, float scale) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = to_f32(a[i]) - to_f32(b[i]);
+    acc += fabsf(d);
+    if (da) da[i] = Cvt<T>::from(d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_version(void) { return MI_RESTORE_VERSION; }
+extern "C" const char* mi_last_error(void) { return g_err; }
+
+extern "C" int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  MI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+  MI_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw: buffers must be 16-byte aligned");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.0f - powf(beta2, (float)step));
+  int blocks = cdiv(n, 256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_cast(const void* src, int sdt, void* dst, int ddt, int64_t n, void* stream) {
+  MI_CHECK_ARG(src && dst && n > 0, "cast: bad arguments");
+  int blocks = cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (sdt == MI_F32 && ddt == MI_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
+  else if (sdt == MI_BF16 && ddt == MI_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+  else if (sdt == MI_F32 && ddt == MI_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (sdt == MI_BF16 && ddt == MI_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, n);
+  else { set_error("cast: bad dtypes %d -> %d", sdt, ddt); return MI_ERR_ARG; }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+// loss[0] += mean|a-b| ; uses loss[1..] as scratch: caller passes a float buffer of >= 1+1024 entries
+extern "C" int mi_l1_loss(const void* a, const void* b, void* da, float* loss, int64_t n, float scale, int dtype,
+                          void* stream) {
+  MI_CHECK_ARG(a && b && loss && n > 0, "l1_loss: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = cdiv(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (dtype == MI_F32)
+    hipLaunchKernelGGL((l1_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)da,
+                       loss + 1, n, scale);
+  else if (dtype == MI_BF16)
+    hipLaunchKernelGGL((l1_kernel<bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)da,
+                       loss + 1, n, scale);
+  else { set_error("l1_loss: bad dtype"); return MI_ERR_ARG; }
+  MI_LAUNCH_CHECK();
+  return launch_reduce_rows(loss + 1, loss, blocks, 1, 1, 1, 1.0f / (float)n, st);
+}

@@ -1,0 +1,279 @@
+"""Tensor-level wrappers over the C-ABI (``include/mi_restore.h``).
+
+PyTorch is plumbing here: it owns device memory (outputs, saved blobs and workspaces are torch
+tensors, so the caching allocator and stream semantics apply) and supplies the current HIP stream.
+All compute happens in ``libmi_restore.so``.  CPU tensors are rejected: there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.MI_F32
+    if t.dtype == torch.bfloat16:
+        return L.MI_BF16
+    raise TypeError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _gpu(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("image_restoration_amd ops run on the MI355X only (got a CPU tensor); "
+                               "the CPU restatement lives in oracle/ and is test infrastructure")
+        if not t.is_contiguous():
+            raise RuntimeError("image_restoration_amd ops need contiguous NCHW tensors")
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: Optional[Tensor], what: str) -> Optional[Tensor]:
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32 (parameters and their gradients stay fp32), got {t.dtype}")
+    return t
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _blob(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def ln_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], with_bias: bool, want_stats: bool = True):
+    _gpu(x, w, b)
+    _f32(w, "LayerNorm weight"); _f32(b, "LayerNorm bias")
+    B, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((B, H * W), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    L.check(L.lib().mi_ln_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), B, Cc, H * W, int(with_bias), _dt(x),
+                              _stream()), "ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor], with_bias: bool,
+           dw: Tensor, db: Optional[Tensor], accumulate: bool) -> Tensor:
+    _gpu(dy, x, w, mean, rstd, dres, dw, db)
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    ws = _blob(L.lib().mi_ln_bwd_workspace(B, Cc, H * W), x.device)
+    L.check(L.lib().mi_ln_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), B, Cc, H * W,
+                              int(with_bias), int(accumulate), _dt(x), _p(ws), _stream()), "ln_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- depthwise conv
+def dwconv_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
+    _gpu(x, w, bias)
+    B, Cc, H, W = x.shape
+    ks = w.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().mi_dwconv_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cc, H, W, ks, _dt(x), _stream()), "dwconv_fwd")
+    return y
+
+
+def dwconv_gate_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], want_y: bool = True):
+    _gpu(x, w, bias)
+    B, C2, H, W = x.shape
+    ks = w.shape[-1]
+    y = torch.empty_like(x) if want_y else None
+    g = torch.empty((B, C2 // 2, H, W), dtype=x.dtype, device=x.device)
+    L.check(L.lib().mi_dwconv_gate_fwd(_p(x), _p(w), _p(bias), _p(y), _p(g), B, C2, H, W, ks, _dt(x), _stream()),
+            "dwconv_gate_fwd")
+    return y, g
+
+
+def dwconv_bwd(dy: Tensor, x: Tensor, w: Tensor, has_bias: bool):
+    _gpu(dy, x, w)
+    B, Cc, H, W = x.shape
+    ks = w.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_bias else None
+    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, Cc, H, W, ks), x.device)
+    L.check(L.lib().mi_dwconv_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Cc, H, W, ks, 0, _dt(x), _p(ws),
+                                  _stream()), "dwconv_bwd")
+    return dx, dw, db
+
+
+def dwconv_gate_bwd(dg: Tensor, y: Tensor, x: Tensor, w: Tensor, has_bias: bool):
+    _gpu(dg, y, x, w)
+    B, C2, H, W = x.shape
+    ks = w.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    db = torch.empty(C2, dtype=torch.float32, device=x.device) if has_bias else None
+    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
+    L.check(L.lib().mi_dwconv_gate_bwd(_p(dg), _p(y), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, C2, H, W, ks, 0, _dt(x),
+                                       _p(ws), _stream()), "dwconv_gate_bwd")
+    return dx, dw, db
+
+
+# ----------------------------------------------------------------------------- pointwise GEMM / Gram
+def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+            transposed: bool = False, x2: Optional[Tensor] = None) -> Tensor:
+    """y = W x (+bias)(+residual).  x [B,K,H,W]; w [M,K(,1,1)] or, transposed, [K,M(,1,1)] used as W^T.
+    x2: optional second K-panel (channel concat without the concat)."""
+    _gpu(x, w, bias, residual, x2)
+    _f32(w, "1x1 weight"); _f32(bias, "1x1 bias")
+    B, K1, H, W = x.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    N = H * W
+    w2 = w.reshape(w.shape[0], -1)
+    M = w2.shape[1] if transposed else w2.shape[0]
+    assert (w2.shape[0] if transposed else w2.shape[1]) == K1 + K2, "weight/input channel mismatch"
+    y = torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
+    d = L.PwDesc()
+    d.x1, d.x1_bs, d.x1_gs, d.k1 = _p(x), K1 * N, 0, K1
+    d.x2, d.x2_bs, d.x2_gs, d.k2 = _p(x2), K2 * N, 0, K2
+    d.w, d.w_bs, d.w_gs = _p(w2), 0, 0
+    d.w_sm, d.w_sk = (1, w2.shape[1]) if transposed else (w2.shape[1], 1)
+    d.bias, d.bias_gs = _p(bias), 0
+    d.r, d.r_bs, d.r_gs = _p(residual), M * N, 0
+    d.y, d.y_bs, d.y_gs = _p(y), M * N, 0
+    d.m, d.n, d.batch, d.groups, d.dtype = M, N, B, 1, _dt(x)
+    L.check(L.lib().mi_pw_gemm(C.byref(d), _stream()), "pw_gemm")
+    return y
+
+
+def gram(a: Tensor, b: Tensor, groups: int = 1, sum_batch: bool = False, want_sumsq: bool = False):
+    """G[z][i][j] = sum_n a[z][i][n] b[z][j][n] with a,b [B, groups*m, H, W] split head-major into groups."""
+    _gpu(a, b)
+    B, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    N = H * W
+    ma, mb = Ca // groups, Cb // groups
+    Z = groups if sum_batch else B * groups
+    out = torch.empty((Z, ma, mb), dtype=torch.float32, device=a.device)
+    ss = torch.empty((B * groups, ma + mb), dtype=torch.float32, device=a.device) if want_sumsq else None
+    d = L.GramDesc()
+    d.a, d.a_bs, d.a_gs, d.ma = _p(a), Ca * N, ma * N, ma
+    d.b, d.b_bs, d.b_gs, d.mb = _p(b), Cb * N, mb * N, mb
+    d.n, d.batch, d.groups, d.dtype = N, B, groups, _dt(a)
+    d.sum_batch, d.accumulate = int(sum_batch), 0
+    d.out, d.out_ld, d.out_zs, d.sumsq = _p(out), mb, ma * mb, _p(ss)
+    ws = _blob(L.lib().mi_gram_workspace(C.byref(d)), a.device)
+    L.check(L.lib().mi_gram(C.byref(d), _p(ws), _stream()), "gram")
+    return (out, ss) if want_sumsq else out
+
+
+# ----------------------------------------------------------------------------- MDTA / GDFN modules
+MdtaParamsT = Tuple[Tensor, Tensor, Optional[Tensor], Tensor, Optional[Tensor], Tensor, Optional[Tensor]]
+GdfnParamsT = Tuple[Tensor, Optional[Tensor], Tensor, Optional[Tensor], Tensor, Optional[Tensor]]
+
+
+def _mdta_shape(x: Tensor, heads: int, ks: int) -> L.MdtaShape:
+    B, Cc, H, W = x.shape
+    return L.MdtaShape(B, Cc, heads, H, W, _dt(x), ks)
+
+
+def _mdta_params(p: Sequence[Optional[Tensor]]) -> L.MdtaParams:
+    for t in p:
+        _f32(t, "MDTA parameter")
+    return L.MdtaParams(*[_p(t) for t in p])
+
+
+def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: int, need_saved: bool):
+    """params = (temperature, qkv.weight, qkv.bias, qkv_dwconv.weight, qkv_dwconv.bias, project_out.weight, .bias)."""
+    _gpu(x, residual, *params)
+    ks = params[3].shape[-1]
+    s = _mdta_shape(x, heads, ks)
+    lib = L.lib()
+    out = torch.empty_like(x)
+    saved = _blob(lib.mi_mdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
+    ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
+    pp = _mdta_params(params)
+    L.check(lib.mi_mdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
+            "mdta_fwd")
+    return out, saved
+
+
+def mdta_bwd(x: Tensor, dout: Tensor, params: MdtaParamsT, heads: int, saved: Tensor,
+             grads: Sequence[Optional[Tensor]], accumulate: bool) -> Tensor:
+    _gpu(x, dout, saved, *params, *grads)
+    ks = params[3].shape[-1]
+    s = _mdta_shape(x, heads, ks)
+    lib = L.lib()
+    dx = torch.empty_like(x)
+    ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
+    pp = _mdta_params(params)
+    for t in grads:
+        _f32(t, "MDTA gradient")
+    gg = L.MdtaGrads(*[_p(t) for t in grads], int(accumulate))
+    L.check(lib.mi_mdta_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
+            "mdta_bwd")
+    return dx
+
+
+def _gdfn_shape(x: Tensor, hidden: int, ks: int) -> L.GdfnShape:
+    B, Cc, H, W = x.shape
+    return L.GdfnShape(B, Cc, hidden, H, W, _dt(x), ks)
+
+
+def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool):
+    """params = (project_in.weight, .bias, dwconv.weight, .bias, project_out.weight, .bias)."""
+    _gpu(x, residual, *params)
+    for t in params:
+        _f32(t, "GDFN parameter")
+    hidden, ks = params[4].shape[1], params[2].shape[-1]
+    s = _gdfn_shape(x, hidden, ks)
+    lib = L.lib()
+    out = torch.empty_like(x)
+    saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(s)), x.device) if need_saved else None
+    ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+    pp = L.GdfnParams(*[_p(t) for t in params])
+    L.check(lib.mi_gdfn_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
+            "gdfn_fwd")
+    return out, saved
+
+
+def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads: Sequence[Optional[Tensor]],
+             accumulate: bool) -> Tensor:
+    _gpu(x, dout, saved, *params, *grads)
+    hidden, ks = params[4].shape[1], params[2].shape[-1]
+    s = _gdfn_shape(x, hidden, ks)
+    lib = L.lib()
+    dx = torch.empty_like(x)
+    ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+    pp = L.GdfnParams(*[_p(t) for t in params])
+    for t in grads:
+        _f32(t, "GDFN gradient")
+    gg = L.GdfnGrads(*[_p(t) for t in grads], int(accumulate))
+    L.check(lib.mi_gdfn_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
+            "gdfn_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- training-step tail
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
+               weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+    _gpu(p, g, m, v)
+    L.check(L.lib().mi_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
+                                  grad_scale, _stream()), "adamw_step")
+
+
+def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
+    """mean|a-b| and (optionally) its gradient w.r.t. a times ``scale``; loss returned as a 1-element fp32 tensor."""
+    _gpu(a, b)
+    buf = torch.zeros(1 + 1024, dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    n = a.numel()
+    L.check(L.lib().mi_l1_loss(_p(a), _p(b), _p(da), _p(buf), n, scale / n, _dt(a), _stream()), "l1_loss")
+    return buf[:1], da

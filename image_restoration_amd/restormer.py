@@ -1,0 +1,431 @@
+"""Drop-in replacements for the block classes of the reference's ``Restormer.py``.
+
+Same class names, constructor arguments, parameter/buffer names and shapes (``state_dict``
+interchangeable) and ``forward`` signatures as Restormer.py:25-284; ``forward`` runs
+the gfx950 kernels through the C-ABI instead of ATen ops.  The conv/LayerNorm submodules are kept
+only as parameter containers (so initialisation and key names are the reference's); they are never
+called.  Activations may be float32 (exact-fp32 MFMA path, the parity path) or bfloat16 (bf16 MFMA,
+fp32 accumulate); parameters and their gradients stay float32.
+
+Gradient accumulation: if every parameter of a module carries a ``main_grad`` attribute (a float32
+tensor of the parameter's shape, e.g. a view into a flat DDP bucket), backward accumulates into it
+in place and reports no autograd gradient for the parameters; otherwise ordinary ``.grad`` flow.
+"""
+from __future__ import annotations
+
+import numbers
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _main_grads(params: Sequence[Optional[Tensor]]) -> Optional[List[Optional[Tensor]]]:
+    """main_grad buffers if every present parameter has one, else None."""
+    out = []
+    for p in params:
+        if p is None:
+            out.append(None)
+            continue
+        mg = getattr(p, "main_grad", None)
+        if mg is None:
+            return None
+        out.append(mg)
+    return out
+
+
+def _fresh_grads(params: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]]:
+    return [None if p is None else torch.empty_like(p) for p in params]
+
+
+# ======================================================================================
+# autograd glue
+# ======================================================================================
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        need = any(ctx.needs_input_grad)
+        y, mean, rstd = ops.ln_fwd(x, weight, bias, bias is not None, want_stats=need)
+        if need:
+            ctx.save_for_backward(x, weight, mean, rstd)
+            ctx.with_bias = bias is not None
+            ctx.mg = _main_grads((weight, bias))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        acc = ctx.mg is not None
+        dw, db = ctx.mg if acc else (torch.empty_like(weight), torch.empty_like(weight) if ctx.with_bias else None)
+        dx = ops.ln_bwd(dy.contiguous(), x, weight, mean, rstd, None, ctx.with_bias, dw, db, acc)
+        if acc:
+            return dx, None, None
+        return dx, dw, db
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, heads, *params):
+        need = any(ctx.needs_input_grad)
+        out, saved = ops.mdta_fwd(x, None, params, heads, need)
+        if need:
+            ctx.heads = heads
+            ctx.mg = _main_grads(params)
+            ctx.n_params = len(params)
+            ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
+            ctx.present = [p is not None for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, saved, *rest = ctx.saved_tensors
+        it = iter(rest)
+        params = tuple(next(it) if pr else None for pr in ctx.present)
+        acc = ctx.mg is not None
+        grads = ctx.mg if acc else _fresh_grads(params)
+        dx = ops.mdta_bwd(x, dout.contiguous(), params, ctx.heads, saved, grads, acc)
+        return (dx, None) + tuple(None if acc else g for g in grads)
+
+
+class _FeedForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        need = any(ctx.needs_input_grad)
+        out, saved = ops.gdfn_fwd(x, None, params, need)
+        if need:
+            ctx.mg = _main_grads(params)
+            ctx.save_for_backward(x, saved, *[p for p in params if p is not None])
+            ctx.present = [p is not None for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, saved, *rest = ctx.saved_tensors
+        it = iter(rest)
+        params = tuple(next(it) if pr else None for pr in ctx.present)
+        acc = ctx.mg is not None
+        grads = ctx.mg if acc else _fresh_grads(params)
+        dx = ops.gdfn_bwd(x, dout.contiguous(), params, saved, grads, acc)
+        return (dx,) + tuple(None if acc else g for g in grads)
+
+
+class _BlockFn(torch.autograd.Function):
+    """x + attn(norm1(x)) ; + ffn(norm2(.))   (Restormer.py:146-150) with both residual adds fused into the
+    producing 1x1 GEMM epilogues (forward) and into the LayerNorm backward (backward)."""
+
+    N_LN, N_ATT, N_FFN = 2, 7, 6
+
+    @staticmethod
+    def forward(ctx, x, heads, *params):
+        n1 = params[0:2]
+        att = params[2:9]
+        n2 = params[9:11]
+        ffn = params[11:17]
+        need = any(ctx.needs_input_grad)
+        wb = n1[1] is not None
+        xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
+        y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
+        yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
+        out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
+        if need:
+            ctx.heads, ctx.wb = heads, wb
+            ctx.mg = _main_grads(params)
+            ctx.present = [p is not None for p in params]
+            ctx.save_for_backward(x, xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f, *[p for p in params if p is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f, *rest = ctx.saved_tensors
+        it = iter(rest)
+        params = tuple(next(it) if pr else None for pr in ctx.present)
+        acc = ctx.mg is not None
+        grads = ctx.mg if acc else _fresh_grads(params)
+        n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
+        g1, ga, g2, gf = grads[0:2], grads[2:9], grads[9:11], grads[11:17]
+        dout = dout.contiguous()
+        dyn = ops.gdfn_bwd(yn, dout, ffn, sv_f, gf, acc)
+        dy = ops.ln_bwd(dyn, y, n2[0], mean2, rstd2, dout, ctx.wb, g2[0], g2[1], acc)
+        dxn = ops.mdta_bwd(xn, dy, att, ctx.heads, sv_a, ga, acc)
+        dx = ops.ln_bwd(dxn, x, n1[0], mean1, rstd1, dy, ctx.wb, g1[0], g1[1], acc)
+        return (dx, None) + tuple(None if acc else g for g in grads)
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 conv over an optional channel concat [x1 ; x2] without materialising the concat
+    (Restormer.py:223,228 reduce_chan_level{3,2} applied to torch.cat, :259-266)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias):
+        y = ops.conv1x1(x1, weight, bias, None, False, x2)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x1, x2, weight)
+            ctx.has_bias = bias is not None
+            ctx.mg = _main_grads((weight, bias))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        k1 = x1.shape[1]
+        w2 = weight.reshape(weight.shape[0], -1)
+        # the two panels' weights are column blocks of one [M, K1+K2] matrix, used in place (row stride K1+K2)
+        dx1 = _dgrad_panel(dy, w2, 0, k1)
+        dx2 = _dgrad_panel(dy, w2, k1, w2.shape[1] - k1) if x2 is not None else None
+        acc = ctx.mg is not None
+        dw = ctx.mg[0] if acc else torch.empty_like(weight)
+        _wgrad_panels(dy, x1, x2, dw.reshape(w2.shape), acc)
+        db = None
+        if ctx.has_bias:
+            s = dy.float().sum(dim=(0, 2, 3))
+            if acc:
+                ctx.mg[1].add_(s)
+            else:
+                db = s
+        return dx1, dx2, (None if acc else dw), db
+
+
+def _dgrad_panel(dy: Tensor, w2: Tensor, k0: int, k: int) -> Tensor:
+    """dx[:, k0:k0+k] = W[:, k0:k0+k]^T dy  using the column block in place (row stride stays K1+K2)."""
+    import ctypes as C
+    from . import _lib as L
+    B, M, H, W = dy.shape
+    N = H * W
+    dx = torch.empty((B, k, H, W), dtype=dy.dtype, device=dy.device)
+    d = L.PwDesc()
+    d.x1, d.x1_bs, d.k1 = dy.data_ptr(), M * N, M
+    d.w = w2.data_ptr() + 4 * k0
+    d.w_sm, d.w_sk = 1, w2.shape[1]
+    d.y, d.y_bs = dx.data_ptr(), k * N
+    d.m, d.n, d.batch, d.groups, d.dtype = k, N, B, 1, ops._dt(dy)
+    L.check(L.lib().mi_pw_gemm(C.byref(d), ops._stream()), "pw_gemm(dgrad panel)")
+    return dx
+
+
+def _wgrad_panels(dy: Tensor, x1: Tensor, x2: Optional[Tensor], dw2: Tensor, accumulate: bool) -> None:
+    import ctypes as C
+    from . import _lib as L
+    B, M, H, W = dy.shape
+    N = H * W
+    ld = dw2.shape[1]
+    k0 = 0
+    for xp in (x1, x2):
+        if xp is None:
+            continue
+        k = xp.shape[1]
+        d = L.GramDesc()
+        d.a, d.a_bs, d.ma = dy.data_ptr(), M * N, M
+        d.b, d.b_bs, d.mb = xp.data_ptr(), k * N, k
+        d.n, d.batch, d.groups, d.dtype = N, B, 1, ops._dt(dy)
+        d.sum_batch, d.accumulate = 1, int(accumulate)
+        d.out, d.out_ld, d.out_zs = dw2.data_ptr() + 4 * k0, ld, 0
+        ws = ops._blob(L.lib().mi_gram_workspace(C.byref(d)), dy.device)
+        L.check(L.lib().mi_gram(C.byref(d), ws.data_ptr(), ops._stream()), "gram(wgrad panel)")
+        k0 += k
+
+
+# ======================================================================================
+# modules (reference interface)
+# ======================================================================================
+def _shape1(normalized_shape):
+    if isinstance(normalized_shape, numbers.Integral):
+        normalized_shape = (normalized_shape,)
+    normalized_shape = torch.Size(normalized_shape)
+    assert len(normalized_shape) == 1
+    return normalized_shape
+
+
+class BiasFree_LayerNorm(nn.Module):
+    """Parameter holder for the bias-free flavour (Restormer.py:25-39)."""
+
+    def __init__(self, normalized_shape):
+        super().__init__()
+        self.normalized_shape = _shape1(normalized_shape)
+        self.weight = nn.Parameter(torch.ones(self.normalized_shape))
+
+
+class WithBias_LayerNorm(nn.Module):
+    """Parameter holder for the with-bias flavour (Restormer.py:41-57)."""
+
+    def __init__(self, normalized_shape):
+        super().__init__()
+        self.normalized_shape = _shape1(normalized_shape)
+        self.weight = nn.Parameter(torch.ones(self.normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(self.normalized_shape))
+
+
+class LayerNorm(nn.Module):
+    """Per-pixel LayerNorm over channels of an NCHW map (Restormer.py:60-70)."""
+
+    def __init__(self, dim, LayerNorm_type):
+        super().__init__()
+        self.body = BiasFree_LayerNorm(dim) if LayerNorm_type == 'BiasFree' else WithBias_LayerNorm(dim)
+
+    def _params(self):
+        return self.body.weight, getattr(self.body, "bias", None)
+
+    def forward(self, x):
+        return _LayerNormFn.apply(x, *self._params())
+
+
+class FeedForward(nn.Module):
+    """GDFN (Restormer.py:76-93)."""
+
+    def __init__(self, dim, ffn_expansion_factor, bias):
+        super().__init__()
+        hidden_features = int(dim * ffn_expansion_factor)
+        self.project_in = nn.Conv2d(dim, hidden_features * 2, kernel_size=1, bias=bias)
+        self.dwconv = nn.Conv2d(hidden_features * 2, hidden_features * 2, kernel_size=3, stride=1, padding=1,
+                                groups=hidden_features * 2, bias=bias)
+        self.project_out = nn.Conv2d(hidden_features, dim, kernel_size=1, bias=bias)
+
+    def _params(self):
+        return (self.project_in.weight, self.project_in.bias, self.dwconv.weight, self.dwconv.bias,
+                self.project_out.weight, self.project_out.bias)
+
+    def forward(self, x):
+        return _FeedForwardFn.apply(x, *self._params())
+
+
+class Attention(nn.Module):
+    """MDTA (Restormer.py:99-132)."""
+
+    def __init__(self, dim, num_heads, bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Conv2d(dim, dim * 3, kernel_size=1, bias=bias)
+        self.qkv_dwconv = nn.Conv2d(dim * 3, dim * 3, kernel_size=3, stride=1, padding=1, groups=dim * 3, bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, kernel_size=1, bias=bias)
+
+    def _params(self):
+        return (self.temperature, self.qkv.weight, self.qkv.bias, self.qkv_dwconv.weight, self.qkv_dwconv.bias,
+                self.project_out.weight, self.project_out.bias)
+
+    def forward(self, x):
+        return _AttentionFn.apply(x, self.num_heads, *self._params())
+
+
+class TransformerBlock(nn.Module):
+    """norm1 -> attn -> +x -> norm2 -> ffn -> +x (Restormer.py:137-150), one fused autograd node."""
+
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, LayerNorm_type)
+        self.attn = Attention(dim, num_heads, bias)
+        self.norm2 = LayerNorm(dim, LayerNorm_type)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+    def forward(self, x):
+        params = self.norm1._params() + self.attn._params() + self.norm2._params() + self.ffn._params()
+        return _BlockFn.apply(x, self.attn.num_heads, *params)
+
+
+def _conv2d(x: Tensor, conv: nn.Conv2d) -> Tensor:
+    """U-Net glue convolution (dense 3x3): SURVEY 8(f) row f1 ("next"), still a PyTorch-ROCm op this round.
+    Parameters stay fp32; they are cast to the activation dtype for the call."""
+    w = conv.weight if conv.weight.dtype == x.dtype else conv.weight.to(x.dtype)
+    b = conv.bias
+    if b is not None and b.dtype != x.dtype:
+        b = b.to(x.dtype)
+    return F.conv2d(x, w, b, conv.stride, conv.padding)
+
+
+class OverlapPatchEmbed(nn.Module):
+    """3x3 conv embedding (Restormer.py:156-165)."""
+
+    def __init__(self, in_c=3, embed_dim=48, bias=False):
+        super().__init__()
+        self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=3, stride=1, padding=1, bias=bias)
+
+    def forward(self, x):
+        return _conv2d(x, self.proj)
+
+
+class Downsample(nn.Module):
+    """3x3 conv C->C/2 + PixelUnshuffle(2) (Restormer.py:171-179)."""
+
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat // 2, kernel_size=3, stride=1, padding=1, bias=False),
+                                  nn.PixelUnshuffle(2))
+
+    def forward(self, x):
+        return F.pixel_unshuffle(_conv2d(x, self.body[0]), 2).contiguous()
+
+
+class Upsample(nn.Module):
+    """3x3 conv C->2C + PixelShuffle(2) (Restormer.py:181-189)."""
+
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat * 2, kernel_size=3, stride=1, padding=1, bias=False),
+                                  nn.PixelShuffle(2))
+
+    def forward(self, x):
+        return F.pixel_shuffle(_conv2d(x, self.body[0]), 2).contiguous()
+
+
+def _stage(dim, heads, n, ffn, bias, ln):
+    return nn.Sequential(*[TransformerBlock(dim=dim, num_heads=heads, ffn_expansion_factor=ffn, bias=bias,
+                                            LayerNorm_type=ln) for _ in range(n)])
+
+
+class Restormer(nn.Module):
+    """The reference U-Net (Restormer.py:193-284) over the HIP-backed blocks; same constructor and state_dict."""
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
+                 heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias',
+                 dual_pixel_task=False):
+        super().__init__()
+        f, b, ln = ffn_expansion_factor, bias, LayerNorm_type
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.encoder_level1 = _stage(dim, heads[0], num_blocks[0], f, b, ln)
+        self.down1_2 = Downsample(dim)
+        self.encoder_level2 = _stage(int(dim * 2 ** 1), heads[1], num_blocks[1], f, b, ln)
+        self.down2_3 = Downsample(int(dim * 2 ** 1))
+        self.encoder_level3 = _stage(int(dim * 2 ** 2), heads[2], num_blocks[2], f, b, ln)
+        self.down3_4 = Downsample(int(dim * 2 ** 2))
+        self.latent = _stage(int(dim * 2 ** 3), heads[3], num_blocks[3], f, b, ln)
+        self.up4_3 = Upsample(int(dim * 2 ** 3))
+        self.reduce_chan_level3 = nn.Conv2d(int(dim * 2 ** 3), int(dim * 2 ** 2), kernel_size=1, bias=bias)
+        self.decoder_level3 = _stage(int(dim * 2 ** 2), heads[2], num_blocks[2], f, b, ln)
+        self.up3_2 = Upsample(int(dim * 2 ** 2))
+        self.reduce_chan_level2 = nn.Conv2d(int(dim * 2 ** 2), int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.decoder_level2 = _stage(int(dim * 2 ** 1), heads[1], num_blocks[1], f, b, ln)
+        self.up2_1 = Upsample(int(dim * 2 ** 1))
+        self.decoder_level1 = _stage(int(dim * 2 ** 1), heads[0], num_blocks[0], f, b, ln)
+        self.refinement = _stage(int(dim * 2 ** 1), heads[0], num_refinement_blocks, f, b, ln)
+        self.dual_pixel_task = dual_pixel_task
+        if self.dual_pixel_task:
+            self.skip_conv = nn.Conv2d(dim, int(dim * 2 ** 1), kernel_size=1, bias=bias)
+        self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+
+    def forward(self, inp_img):
+        inp_enc_level1 = self.patch_embed(inp_img)
+        out_enc_level1 = self.encoder_level1(inp_enc_level1)
+        out_enc_level2 = self.encoder_level2(self.down1_2(out_enc_level1))
+        out_enc_level3 = self.encoder_level3(self.down2_3(out_enc_level2))
+        latent = self.latent(self.down3_4(out_enc_level3))
+
+        # concat-free channel reduce: two K-panels of one 1x1 GEMM (Restormer.py:259-261)
+        inp_dec_level3 = _Conv1x1Fn.apply(self.up4_3(latent), out_enc_level3, self.reduce_chan_level3.weight,
+                                          self.reduce_chan_level3.bias)
+        out_dec_level3 = self.decoder_level3(inp_dec_level3)
+        inp_dec_level2 = _Conv1x1Fn.apply(self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
+                                          self.reduce_chan_level2.bias)
+        out_dec_level2 = self.decoder_level2(inp_dec_level2)
+        inp_dec_level1 = torch.cat([self.up2_1(out_dec_level2), out_enc_level1], 1)
+        out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
+
+        if self.dual_pixel_task:
+            out_dec_level1 = out_dec_level1 + _Conv1x1Fn.apply(inp_enc_level1, None, self.skip_conv.weight,
+                                                               self.skip_conv.bias)
+            return _conv2d(out_dec_level1, self.output)
+        return _conv2d(out_dec_level1, self.output) + inp_img

@@ -1,0 +1,212 @@
+"""GPU parity of the kernel archetypes against the CPU oracle / plain torch fp64 restatements.
+fp32 activations: exact-fp32 MFMA path, tolerance 2e-5 relative to max|ref| (GEMM reductions up to K~2000);
+bf16 activations: bf16 storage, fp32 accumulate, tolerance 2e-2.  Integer-valued data must be EXACT
+(catches any MFMA fragment / transpose-read mapping error)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restormer_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2.5e-2}
+
+
+def ops():
+    from image_restoration_amd import ops as o
+    return o
+
+
+def rel(got, ref):
+    ref = ref.double()
+    return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rnd(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def ints(shape, seed, lo=-3, hi=4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("wb", [True, False])
+@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 16, 5, 7), (2, 96, 8, 32), (1, 384, 4, 8), (1, 192, 3, 3)])
+def test_layernorm_fwd_bwd(dtype, wb, shape):
+    o = ops()
+    B, C, H, W = shape
+    x = (rnd(shape, 1) * 1.5 + 0.3).to(dtype)
+    w = 1.0 + 0.2 * rnd((C,), 2)
+    b = 0.1 * rnd((C,), 3) if wb else None
+    dy = rnd(shape, 4).to(dtype)
+    dres = rnd(shape, 5).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if wb else None
+    yr = R.layernorm_nchw(xr, wr, br, "WithBias" if wb else "BiasFree")
+    yr.backward(dy.double())
+    y, mean, rstd = o.ln_fwd(x.to(DEV), w.to(DEV), b.to(DEV) if wb else None, wb)
+    assert rel(y, yr) < TOL[dtype]
+    dw = torch.zeros(C, device=DEV)
+    db = torch.zeros(C, device=DEV) if wb else None
+    dx = o.ln_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dres.to(DEV), wb, dw, db, False)
+    assert rel(dx, xr.grad + dres.double()) < TOL[dtype]
+    assert rel(dw, wr.grad) < TOL[dtype]
+    if wb:
+        assert rel(db, br.grad) < TOL[dtype]
+    # accumulate mode adds on top
+    dw2 = dw.clone()
+    o.ln_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None, wb, dw2, db.clone() if wb else None, True)
+    assert rel(dw2, 2 * wr.grad) < TOL[dtype]
+
+
+# --------------------------------------------------------------------------- depthwise conv
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ks", [3, 7])
+@pytest.mark.parametrize("shape", [(2, 6, 16, 64), (1, 5, 33, 70), (2, 8, 32, 32), (1, 4, 9, 13), (1, 3, 16, 16)])
+def test_dwconv_fwd_bwd(dtype, ks, shape):
+    o = ops()
+    B, C, H, W = shape
+    x = rnd(shape, 11).to(dtype)
+    w = rnd((C, 1, ks, ks), 12) / ks
+    bias = 0.1 * rnd((C,), 13)
+    dy = rnd(shape, 14).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2, groups=C)
+    yr.backward(dy.double())
+    y = o.dwconv_fwd(x.to(DEV), w.to(DEV), bias.to(DEV))
+    assert rel(y, yr) < TOL[dtype]
+    dx, dw, db = o.dwconv_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), True)
+    assert rel(dx, xr.grad) < TOL[dtype]
+    assert rel(dw, wr.grad) < TOL[dtype]
+    assert rel(db, br.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 10, 16, 64), (1, 254, 16, 16), (1, 6, 7, 9)])
+def test_dwconv_gate_fwd_bwd(dtype, shape):
+    o = ops()
+    B, C2, H, W = shape
+    h = C2 // 2
+    x = rnd(shape, 21).to(dtype)
+    w = rnd((C2, 1, 3, 3), 22) / 3
+    dg = rnd((B, h, H, W), 24).to(dtype)
+    y, g = o.dwconv_gate_fwd(x.to(DEV), w.to(DEV), None)
+    yr = F.conv2d(x.double(), w.double(), None, padding=1, groups=C2)
+    assert rel(y, yr) < TOL[dtype]
+    # the gate is evaluated on y as stored; backward oracle starts from the stored y as well
+    ys = y.detach().cpu().double().requires_grad_(True)
+    gr = F.gelu(ys[:, :h]) * ys[:, h:]
+    assert rel(g, gr) < TOL[dtype]
+    gr.backward(dg.double())
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1, groups=C2).backward(ys.grad)
+    dx, dw, db = o.dwconv_gate_bwd(dg.to(DEV), y, x.to(DEV), w.to(DEV), True)
+    assert rel(dx, xr.grad) < TOL[dtype]
+    assert rel(dw, wr.grad) < TOL[dtype]
+    assert rel(db, ys.grad.sum(dim=(0, 2, 3))) < TOL[dtype]
+
+
+# --------------------------------------------------------------------------- pointwise GEMM
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("M,K", [(16, 16), (48, 48), (144, 48), (254, 48), (48, 127), (288, 96), (130, 70), (1152, 384)])
+def test_conv1x1_exact_on_integers(dtype, transposed, M, K):
+    """small-integer operands: every product and partial sum is exactly representable -> results must be EXACT.
+    The weight is asymmetric and non-square so a swapped row/col or a permuted k would show."""
+    o = ops()
+    B, H, W = 2, 8, 16
+    x = ints((B, K, H, W), 31).to(dtype)
+    wmat = ints((M, K), 32, -2, 3)
+    res = ints((B, M, H, W), 33).to(dtype)
+    bias = ints((M,), 34)
+    ref = torch.einsum("mk,bkhw->bmhw", wmat, x.float()) + bias.view(1, -1, 1, 1) + res.float()
+    warg = wmat.t().contiguous() if transposed else wmat
+    y = o.conv1x1(x.to(DEV), warg.to(DEV), bias.to(DEV), res.to(DEV), transposed)
+    assert torch.equal(y.float().cpu(), ref), f"max diff {(y.float().cpu() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(1, 48, 5, 7), (2, 96, 3, 10), (1, 20, 16, 16)])
+def test_conv1x1_ragged_and_two_panels(dtype, shape):
+    """N not a multiple of the vector width / tile, and the concat-free two-panel form."""
+    o = ops()
+    B, K, H, W = shape
+    M, K2 = 37, 24
+    x1 = rnd(shape, 41).to(dtype)
+    x2 = rnd((B, K2, H, W), 42).to(dtype)
+    w = rnd((M, K + K2), 43) / math.sqrt(K + K2)
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), torch.cat([x1, x2], 1).double())
+    y = o.conv1x1(x1.to(DEV), w.to(DEV), None, None, False, x2.to(DEV))
+    assert rel(y, ref) < TOL[dtype]
+    y1 = o.conv1x1(x1.to(DEV), w[:, :K].contiguous().to(DEV))
+    assert rel(y1, torch.einsum("mk,bkhw->bmhw", w[:, :K].double(), x1.double())) < TOL[dtype]
+
+
+# --------------------------------------------------------------------------- Gram
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ma,mb,groups,hw", [(48, 48, 1, (16, 16)), (48, 48, 2, (8, 40)), (96, 96, 1, (32, 32)),
+                                             (16, 16, 8, (4, 4)), (254, 48, 1, (16, 24)), (30, 70, 1, (5, 7))])
+def test_gram_exact_on_integers_and_sumsq(dtype, ma, mb, groups, hw):
+    o = ops()
+    B = 2
+    a = ints((B, groups * ma, *hw), 51, -2, 3).to(dtype)
+    b = ints((B, groups * mb, *hw), 52, -2, 3).to(dtype)
+    af = a.float().reshape(B, groups, ma, -1)
+    bf = b.float().reshape(B, groups, mb, -1)
+    ref = torch.einsum("bgin,bgjn->bgij", af, bf).reshape(B * groups, ma, mb)
+    out, ss = o.gram(a.to(DEV), b.to(DEV), groups, False, True)
+    assert torch.equal(out.cpu(), ref)
+    ssr = torch.cat([af.pow(2).sum(-1), bf.pow(2).sum(-1)], -1).reshape(B * groups, ma + mb)
+    assert torch.equal(ss.cpu(), ssr)
+    if groups == 1:
+        outb = o.gram(a.to(DEV), b.to(DEV), 1, True)
+        assert torch.equal(outb.cpu(), ref.sum(0, keepdim=True))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gram_long_reduction_random(dtype):
+    """split over the pixel axis across many workgroups (64x64 image = 4096 pixels)."""
+    o = ops()
+    a = rnd((2, 144, 64, 64), 61).to(dtype)
+    b = rnd((2, 48, 64, 64), 62).to(dtype)
+    ref = torch.einsum("bin,bjn->ij", a.double().flatten(2), b.double().flatten(2))[None]
+    out = o.gram(a.to(DEV), b.to(DEV), 1, True)
+    assert rel(out, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+# --------------------------------------------------------------------------- AdamW / L1
+def test_adamw_matches_torch():
+    o = ops()
+    n = 10007
+    p = rnd((n,), 71)
+    g = rnd((n,), 72)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=2e-4)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        pt.grad = g * step
+        opt.step()
+        o.adamw_step(pd, (g * step).to(DEV), m, v, 2e-4, step)
+    assert rel(pd, pt.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_l1_loss(dtype):
+    o = ops()
+    a, b = rnd((3, 3, 17, 19), 81).to(dtype), rnd((3, 3, 17, 19), 82).to(dtype)
+    loss, da = o.l1_loss(a.to(DEV), b.to(DEV))
+    ref = (a.double() - b.double()).abs().mean()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    assert rel(da, torch.sign(a.double() - b.double()) / a.numel()) < 1e-2
