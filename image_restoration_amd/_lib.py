@@ -93,9 +93,14 @@ SIGNATURES = {
     "mi_gdfn_bwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, C.POINTER(GdfnGrads), vp, vp,
                               vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
-                                C.c_float, vp]),
+                                C.c_float, fp, vp]),
     "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),
     "mi_l1_loss": (C.c_int, [vp, vp, vp, fp, c_i64, C.c_float, C.c_int, vp]),
+    "mi_prof_enable": (C.c_int, [C.c_int]),
+    "mi_prof_kernel_count": (C.c_int, []),
+    "mi_prof_kernel_name": (C.c_char_p, [C.c_int]),
+    "mi_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(c_i64), C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None

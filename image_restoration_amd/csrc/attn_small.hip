@@ -179,6 +179,7 @@ int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtyp
   const int64_t per = (N + splits - 1) / splits;
   float* part = (float*)ws;
   dim3 grid(C, splits), block(256);
+  ProfScope ps(st, K_CHAN_SUM, (double)B * C * N * dtype_size(dtype), (double)B * C * N);
   if (dtype == MI_F32) hipLaunchKernelGGL((chan_sum_kernel<float>), grid, block, 0, st, (const float*)x, part, B, C, N, per);
   else hipLaunchKernelGGL((chan_sum_kernel<bf16>), grid, block, 0, st, (const bf16*)x, part, B, C, N, per);
   MI_LAUNCH_CHECK();
@@ -191,6 +192,7 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
   const size_t lds = (size_t)c * ld * sizeof(float);
+  ProfScope ps(st, K_ATTN_FOLD, 4.0 * B * (3.0 * C * c + 2.0 * C * C), 2.0 * B * C * (double)c * C);
   hipLaunchKernelGGL(attn_fold_kernel, dim3(B * heads), dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, C, heads,
                      ld);
   MI_LAUNCH_CHECK();
@@ -204,6 +206,7 @@ int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
   const size_t lds = (size_t)c * ld * sizeof(float);
+  ProfScope ps(st, K_ATTN_BWD_SMALL, 4.0 * B * (6.0 * C * c + 3.0 * C * C), 4.0 * B * C * (double)c * C);
   hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(256), lds, st, dM, A, P, nrm, temperature, wo, dwo_part,
                      dtemp_part, wdq, wdk, C, heads, ld);
   MI_LAUNCH_CHECK();

@@ -169,6 +169,18 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 #endif  // __HIPCC__
 
+// ---- optional per-kernel HIP-event profiler (off by default; bench.py's roofline pass turns it on) ----
+enum KernelId {
+  K_LN_FWD = 0, K_LN_BWD, K_DW_FWD, K_DW_GATE_FWD, K_DW_BWD_DATA, K_DW_GATE_BWD_DATA, K_DW_WGRAD, K_PW_GEMM, K_GRAM,
+  K_GRAM_REDUCE, K_ATTN_FOLD, K_ATTN_BWD_SMALL, K_REDUCE_ROWS, K_CHAN_SUM, K_ADAMW, K_CAST, K_L1, K_COUNT
+};
+// Brackets one kernel launch with two events on ITS stream and books its algorithmic bytes / flops.
+struct ProfScope {
+  hipStream_t st; int kid; bool on;
+  ProfScope(hipStream_t stream, int kernel_id, double bytes, double flops);
+  ~ProfScope();
+};
+
 // generic small kernels implemented in util.hip, used by several modules
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld,
                        int accumulate, float scale, hipStream_t st);

@@ -196,6 +196,11 @@ static int dw_launch(DwArgs a, int B, hipStream_t st) {
   const int tiles = a.tiles_x * cdiv(a.H, th);
   const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate);
   dim3 grid(tiles, GATE ? a.hidden : a.Cc, B), block(256);
+  const double plane = (double)B * a.H * a.W * sizeof(T);
+  const int kid = GATE ? K_DW_GATE_FWD : (FLIP ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_FWD);
+  const double chans = GATE ? (a.Cc + (a.out ? a.Cc : 0) + a.hidden)
+                            : (MODE == IN_GATE_BWD ? (a.hidden + 2.0 * a.Cc) : 2.0 * a.Cc);
+  ProfScope ps(st, kid, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
   if (tw == 64) hipLaunchKernelGGL((dwconv_kernel<T, KS, 64, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
   else if (tw == 32) hipLaunchKernelGGL((dwconv_kernel<T, KS, 32, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
   else hipLaunchKernelGGL((dwconv_kernel<T, KS, 16, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
@@ -211,6 +216,9 @@ static int dw_wgrad_launch(DwArgs dya, const void* xin, float* part, int B, int*
   const int tiles = dya.tiles_x * cdiv(dya.H, th);
   *tiles_out = tiles;
   dim3 grid(tiles, dya.Cc), block(256);
+  const double plane = (double)B * dya.H * dya.W * sizeof(T);
+  ProfScope ps(st, K_DW_WGRAD, (MODE == IN_GATE_BWD ? dya.hidden + 2.0 * dya.Cc : 2.0 * dya.Cc) * plane,
+               2.0 * KS * KS * dya.Cc * (double)B * dya.H * dya.W);
   if (tw == 64) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 64, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);
   else if (tw == 32) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 32, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);
   else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 16, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);

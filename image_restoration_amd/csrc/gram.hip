@@ -252,6 +252,10 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   dim3 grid(g.splits, g.tiles_a * g.tiles_b, g.Z), block(256);
   MI_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gram: grid too large");
   const bool ss = d->sumsq != nullptr;
+  const double es = d->dtype == MI_BF16 ? 2.0 : 4.0;
+  {
+  ProfScope ps(st, K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
+               2.0 * d->ma * d->mb * (double)d->n * g.Z);
 #define GRAM_CASE(T, F)                                                                     \
   do {                                                                                      \
     if (ss) hipLaunchKernelGGL((gram_kernel<T, F, true>), grid, block, 0, st, k);           \
@@ -260,7 +264,9 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   if (d->dtype == MI_F32) { if (g.F == 4) GRAM_CASE(float, 4); else GRAM_CASE(float, 2); }
   else { if (g.F == 4) GRAM_CASE(bf16, 4); else GRAM_CASE(bf16, 2); }
 #undef GRAM_CASE
+  }
   MI_LAUNCH_CHECK();
+  ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
   const int zo = d->sum_batch ? d->groups : g.Z;
   const int64_t per = (int64_t)d->ma * d->mb;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 256), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,

@@ -212,6 +212,7 @@ template <typename T, int VEC, bool WB>
 static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, float* mean, float* rstd, int B, int C,
                            int64_t N, hipStream_t st) {
   dim3 grid(cdiv(N, 64 * VEC), B), block(64 * LN_WAVES);
+  ProfScope ps(st, K_LN_FWD, 2.0 * B * C * N * sizeof(T) + (mean ? 8.0 * B * N : 0.0), 8.0 * B * C * N);
 #define LN_FWD_CASE(CPT)                                                                                   \
   hipLaunchKernelGGL((ln_fwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, x, w, b, y, mean, rstd, C, N)
   if (C <= 16) LN_FWD_CASE(2);
@@ -229,6 +230,7 @@ template <typename T, int VEC, bool WB>
 static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float* mean, const float* rstd, const T* dres,
                            T* dx, float* part, int B, int C, int64_t N, int gx, int tpb, int tiles_img, hipStream_t st) {
   dim3 grid(gx, B), block(64 * LN_WAVES);
+  ProfScope ps(st, K_LN_BWD, (dres ? 4.0 : 3.0) * B * C * N * sizeof(T) + 8.0 * B * N, 16.0 * B * C * N);
 #define LN_BWD_CASE(CPT)                                                                                     \
   hipLaunchKernelGGL((ln_bwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, dy, x, w, mean, rstd, dres, dx, part, C, N, \
                      tpb, tiles_img)

@@ -232,6 +232,9 @@ static int pw_launch(const PwK& k, int batch, hipStream_t st) {
   else if (cdiv(k.m, 128) * 128 * 4 <= mmin * 5) tm = 128;
   dim3 grid(cdiv(k.n, PW_TN), cdiv(k.m, tm), batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
+  const double Z = (double)batch * k.groups, kt = k.k1 + k.k2;
+  ProfScope ps(st, K_PW_GEMM, (kt + k.m + (k.r ? k.m : 0)) * (double)k.n * Z * sizeof(T) + 4.0 * k.m * kt,
+               2.0 * k.m * kt * (double)k.n * Z);
   if (tm == 256) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, WT>), grid, block, 0, st, k);
   else if (tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, WT>), grid, block, 0, st, k);
   else hipLaunchKernelGGL((pw_gemm_kernel<T, 1, WT>), grid, block, 0, st, k);

@@ -1,6 +1,10 @@
 // Small shared kernels: deterministic row reduction, AdamW on flat buffers, casts, L1 loss.
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace mi {
@@ -11,6 +15,31 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------- profiler
+struct ProfRec { int kid; double bytes, flops; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_recs;
+static std::atomic<int> g_prof_on{0};
+static const char* const g_kernel_names[K_COUNT] = {
+    "ln_fwd", "ln_bwd", "dwconv_fwd", "dwconv_gate_fwd", "dwconv_bwd_data", "dwconv_gate_bwd_data", "dwconv_wgrad",
+    "pw_gemm", "gram", "gram_reduce", "attn_fold", "attn_bwd_small", "reduce_rows", "chan_sum", "adamw", "cast", "l1_loss"};
+
+ProfScope::ProfScope(hipStream_t stream, int kernel_id, double bytes, double flops)
+    : st(stream), kid(kernel_id), on(g_prof_on.load(std::memory_order_relaxed) != 0) {
+  if (!on) return;
+  ProfRec r{kernel_id, bytes, flops, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+  (void)hipEventRecord(r.e0, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_recs.push_back(r);
+  kid = (int)g_prof_recs.size() - 1;  // reuse the field as the record index for the destructor
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (kid >= 0 && kid < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[kid].e1, st);
 }
 
 // out[c] = (accumulate ? out[c] : 0) + scale * sum_r part[r*ld + c].  One thread per column chunk,
@@ -35,6 +64,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate,
                        float scale, hipStream_t st) {
   if (cols <= 0) return MI_OK;
+  ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + 1) * cols * 4, (double)rows * cols);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, part, out, rows, cols, part_ld,
                      accumulate, scale);
   MI_LAUNCH_CHECK();
@@ -45,7 +75,8 @@ int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    float gscale) {
+                                                    float gscale, const float* __restrict__ dev_scalars) {
+  if (dev_scalars) { lr = dev_scalars[0]; bc1 = dev_scalars[1]; bc2_sqrt = dev_scalars[2]; }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n) {
@@ -105,18 +136,43 @@ __global__ __launch_bounds__(256) void l1_kernel(const T* __restrict__ a, const 
 using namespace mi;
 
 extern "C" int mi_version(void) { return MI_RESTORE_VERSION; }
+
+extern "C" int mi_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof_recs.clear();
+  g_prof_on.store(on ? 1 : 0);
+  return MI_OK;
+}
+extern "C" int mi_prof_kernel_count(void) { return K_COUNT; }
+extern "C" const char* mi_prof_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? g_kernel_names[kid] : ""; }
+extern "C" int mi_prof_collect(double* ms, double* bytes, double* flops, int64_t* launches, int n) {
+  MI_CHECK_ARG(ms && bytes && flops && launches && n >= K_COUNT, "prof_collect: need arrays of %d entries", K_COUNT);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < n; ++i) { ms[i] = 0; bytes[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (auto& r : g_prof_recs) {
+    MI_CHECK_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    MI_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms[r.kid] += t; bytes[r.kid] += r.bytes; flops[r.kid] += r.flops; launches[r.kid] += 1;
+  }
+  return MI_OK;
+}
 extern "C" const char* mi_last_error(void) { return g_err; }
 
 extern "C" int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
-  MI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+                             float eps, float weight_decay, int step, float grad_scale, const float* dev_scalars,
+                             void* stream) {
+  MI_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || dev_scalars), "adamw: bad arguments");
+  if (step < 1) step = 1;
   MI_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw: buffers must be 16-byte aligned");
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float bc2 = sqrtf(1.0f - powf(beta2, (float)step));
   int blocks = cdiv(n, 256 * 4);
   if (blocks > 2048) blocks = 2048;
+  ProfScope ps((hipStream_t)stream, K_ADAMW, 28.0 * n, 12.0 * n);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, grad_scale);
+                     weight_decay, bc1, bc2, grad_scale, dev_scalars);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

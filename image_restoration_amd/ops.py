@@ -263,10 +263,11 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
 
 # ----------------------------------------------------------------------------- training-step tail
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
-               weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
-    _gpu(p, g, m, v)
+               weight_decay: float = 1e-2, grad_scale: float = 1.0, dev_scalars: Optional[Tensor] = None) -> None:
+    """dev_scalars: optional device tensor [lr, 1-b1^t, sqrt(1-b2^t)] that overrides lr/step (graph replay)."""
+    _gpu(p, g, m, v, dev_scalars)
     L.check(L.lib().mi_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
-                                  grad_scale, _stream()), "adamw_step")
+                                  grad_scale, _p(dev_scalars), _stream()), "adamw_step")
 
 
 def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
@@ -277,3 +278,22 @@ def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
     n = a.numel()
     L.check(L.lib().mi_l1_loss(_p(a), _p(b), _p(da), _p(buf), n, scale / n, _dt(a), _stream()), "l1_loss")
     return buf[:1], da
+
+
+# ----------------------------------------------------------------------------- profiler (bench.py roofline pass)
+def prof_enable(on: bool) -> None:
+    L.check(L.lib().mi_prof_enable(int(on)), "prof_enable")
+
+
+def prof_collect():
+    """-> {kernel: dict(ms, bytes, flops, launches)} for kernels launched since prof_enable(True)."""
+    lib = L.lib()
+    n = lib.mi_prof_kernel_count()
+    ms, by, fl = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    cnt = (L.c_i64 * n)()
+    L.check(lib.mi_prof_collect(ms, by, fl, cnt, n), "prof_collect")
+    out = {}
+    for i in range(n):
+        if cnt[i]:
+            out[lib.mi_prof_kernel_name(i).decode()] = dict(ms=ms[i], bytes=by[i], flops=fl[i], launches=int(cnt[i]))
+    return out

@@ -172,15 +172,32 @@ int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, 
  * Training-step tail on flat fp32 buffers (MoCE-IR-main/src/train.py:79-88:
  * AdamW(lr=2e-4), torch defaults betas (0.9,0.999), eps 1e-8, weight_decay 1e-2).
  * p, g, m, v: [n] fp32.  grad_scale multiplies g first (1/world for DDP mean).
+ * dev_scalars (device, may be NULL): {lr, 1-beta1^step, sqrt(1-beta2^step)} read by the kernel
+ * instead of the host lr/step, so that a captured HIP graph can be replayed with new values.
  * ------------------------------------------------------------------------ */
 int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+                  float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  const float* dev_scalars, void* stream);
 
 /* dtype conversion / L1 loss helpers used by the harness */
 int mi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
-/* loss[0] += mean|a-b| ; da = sign(a-b)/n * scale (da may be NULL) */
+/* loss[0] += mean|a-b| ; da = sign(a-b) * scale (da may be NULL); loss must hold 1+1024 floats
+ * (entries 1.. are scratch for the block partials) */
 int mi_l1_loss(const void* a, const void* b, void* da, float* loss, int64_t n, float scale, int dtype,
                void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optional per-kernel profiler (measurement aid for bench.py's roofline object; nothing in the
+ * reference corresponds to it).  When enabled every kernel launch is bracketed by two HIP events
+ * recorded on the stream it is launched on, and its algorithmic HBM bytes / flops are booked.
+ * mi_prof_collect synchronises, fills per-kernel-id totals (arrays of mi_prof_kernel_count()
+ * entries: milliseconds, algorithmic bytes, flops, launches).  mi_prof_enable(1|0) clears records.
+ * Not for use inside HIP-graph capture.
+ * ------------------------------------------------------------------------ */
+int mi_prof_enable(int on);
+int mi_prof_kernel_count(void);
+const char* mi_prof_kernel_name(int kid);
+int mi_prof_collect(double* ms, double* bytes, double* flops, int64_t* launches, int n);
 
 #ifdef __cplusplus
 }

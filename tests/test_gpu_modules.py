@@ -18,7 +18,7 @@ def M():
 
 
 def rel(got, ref):
-    ref = ref.detach().double()
+    ref = ref.detach().cpu().double()
     return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 

@@ -22,7 +22,7 @@ def ops():
 
 
 def rel(got, ref):
-    ref = ref.double()
+    ref = ref.detach().cpu().double()
     return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
@@ -134,6 +134,7 @@ def test_conv1x1_exact_on_integers(dtype, transposed, M, K):
     ref = torch.einsum("mk,bkhw->bmhw", wmat, x.float()) + bias.view(1, -1, 1, 1) + res.float()
     warg = wmat.t().contiguous() if transposed else wmat
     y = o.conv1x1(x.to(DEV), warg.to(DEV), bias.to(DEV), res.to(DEV), transposed)
+    ref = ref.to(dtype).float()  # the fp32 accumulator is exact; only the final store rounds (bf16: |v| > 256)
     assert torch.equal(y.float().cpu(), ref), f"max diff {(y.float().cpu() - ref).abs().max()}"
 
 
