@@ -14,7 +14,7 @@ namespace mi {
 
 constexpr float NORM_EPS = 1e-12f;  // F.normalize eps (Restormer.py:121-122)
 
-constexpr int ATTN_MAX_C = 120;  // c*(c+1)*4 bytes of dynamic LDS + the small static arrays must stay under 64 KiB
+constexpr int ATTN_MAX_C = 128;  // 16x16 threads x 8x8 register tile in the backward glue
 static inline int attn_ld(int c) { return c + 1; }
 
 __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ graw, const float* __restrict__ ss,
@@ -67,81 +67,145 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
   }
 }
 
+// Backward glue.  256 threads form a 16x16 grid; thread (ti,tj) owns dA/dS entries (ti+16a, tj+16b), a,b < 8
+// (c <= 128), kept in registers.  W_o and dM column blocks stream through LDS in RC-row chunks (coalesced rows
+// of c floats), A stays in LDS for the whole kernel.
+constexpr int ATT_RC = 16;
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dM, const float* __restrict__ A,
                                                              const float* __restrict__ P, const float* __restrict__ nrm,
                                                              const float* __restrict__ temperature,
                                                              const float* __restrict__ wo, float* __restrict__ dwo_part,
                                                              float* __restrict__ dtemp_part, float* __restrict__ wdq,
                                                              float* __restrict__ wdk, int C, int heads, int ld) {
-  extern __shared__ float sm[];  // dA -> dS, [c][ld]
-  __shared__ float rq[128], rk[128], red[4];
+  extern __shared__ float sm[];
   const int c = C / heads;
+  float* As = sm;                          // [c][ld]
+  float* Wt = As + c * ld;                 // [RC][c]   W_o[r][h*c + i]
+  float* Dt = Wt + ATT_RC * c;             // [RC][c]   dM[r][h*c + j]
+  float* colp = Dt + ATT_RC * c;           // [16][c]   per-ti partial column sums
+  float* rqs = colp + 16 * c;              // [c]
+  float* rks = rqs + c;                    // [c]
+  float* red = rks + c;                    // [4]
   const int z = blockIdx.x, b = z / heads, h = z - b * heads;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ti = t >> 4, tj = t & 15;
   const float temp = temperature[h];
   const float* dMb = dM + (int64_t)b * C * C;
   const float* Az = A + (int64_t)z * c * c;
   const float* Pz = P + (int64_t)z * c * c;
   const float* nz = nrm + (int64_t)z * 2 * c;
-
-  // dWo_part[b][r][h*c+i] = sum_j dM[r][h*c+j] * A[i][j]
   float* dwo = dwo_part + (int64_t)b * C * C;
-  for (int e = t; e < C * c; e += 256) {
-    const int r = e / c, i = e - r * c;
-    const float* drow = dMb + (int64_t)r * C + h * c;
-    float acc = 0.f;
-    for (int j = 0; j < c; ++j) acc += drow[j] * Az[i * c + j];
-    dwo[(int64_t)r * C + h * c + i] = acc;
-  }
-  // dA[i][j] = sum_r wo[r][h*c+i] * dM[r][h*c+j]
-  for (int e = t; e < c * c; e += 256) {
-    const int i = e / c, j = e - i * c;
-    float acc = 0.f;
-    for (int r = 0; r < C; ++r) acc += wo[(int64_t)r * C + h * c + i] * dMb[(int64_t)r * C + h * c + j];
-    sm[i * ld + j] = acc;
-  }
-  __syncthreads();
-  // softmax backward per row: dS = A * (dA - sum_j dA*A);  rq_i = sum_j dS*S
-  float tsum = 0.f;
-  for (int i = wv; i < c; i += 4) {
-    float dot = 0.f;
-    for (int j = lane; j < c; j += 64) dot += sm[i * ld + j] * Az[i * c + j];
-    dot = wave_sum(dot);
-    float rqa = 0.f;
-    for (int j = lane; j < c; j += 64) {
-      const float ds = Az[i * c + j] * (sm[i * ld + j] - dot);
-      sm[i * ld + j] = ds;
-      const float pv = Pz[i * c + j];
-      tsum += ds * pv;
-      rqa += ds * pv * temp;
+
+  for (int e = t; e < c * c; e += 256) { const int i = e / c; As[i * ld + (e - i * c)] = Az[e]; }
+
+  float acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) acc[a][bb] = 0.f;
+
+  for (int r0 = 0; r0 < C; r0 += ATT_RC) {
+    __syncthreads();  // previous chunk fully consumed (and As complete on the first pass)
+    for (int e = t; e < ATT_RC * c; e += 256) {
+      const int rr = e / c, col = e - rr * c;
+      const int r = r0 + rr;
+      Wt[e] = r < C ? wo[(int64_t)r * C + h * c + col] : 0.f;
+      Dt[e] = r < C ? dMb[(int64_t)r * C + h * c + col] : 0.f;
     }
-    rqa = wave_sum(rqa);
-    if (lane == 0) rq[i] = rqa;
+    __syncthreads();
+    // dA[i][j] += sum_rr Wt[rr][i] * Dt[rr][j]
+#pragma unroll 4
+    for (int rr = 0; rr < ATT_RC; ++rr) {
+      float wa[8], db[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) wa[a] = (ti + 16 * a < c) ? Wt[rr * c + ti + 16 * a] : 0.f;
+#pragma unroll
+      for (int bb = 0; bb < 8; ++bb) db[bb] = (tj + 16 * bb < c) ? Dt[rr * c + tj + 16 * bb] : 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) acc[a][bb] += wa[a] * db[bb];
+    }
+    // dWo_part[b][r][h*c+i] = sum_j dM[r][h*c+j] * A[i][j]   for the RC rows of this chunk
+    for (int e = t; e < ATT_RC * c; e += 256) {
+      const int rr = e / c, i = e - rr * c;
+      const int r = r0 + rr;
+      if (r < C) {
+        float s2 = 0.f;
+        for (int j = 0; j < c; ++j) s2 += Dt[rr * c + j] * As[i * ld + j];
+        dwo[(int64_t)r * C + h * c + i] = s2;
+      }
+    }
+  }
+
+  // softmax backward: dS = A * (dA - rowdot),  rowdot_i = sum_j dA_ij A_ij  (16 lanes share one ti)
+  float tsum = 0.f;
+  float colsum[8];
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) colsum[bb] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int i = ti + 16 * a;
+    float dot = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      const int j = tj + 16 * bb;
+      if (i < c && j < c) dot += acc[a][bb] * As[i * ld + j];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    float rqa = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      const int j = tj + 16 * bb;
+      float ds = 0.f;
+      if (i < c && j < c) {
+        ds = As[i * ld + j] * (acc[a][bb] - dot);
+        const float pv = Pz[i * c + j];
+        tsum += ds * pv;
+        rqa += ds * pv * temp;
+        colsum[bb] += ds * pv * temp;
+      }
+      acc[a][bb] = ds;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) rqa += __shfl_xor(rqa, o, 64);
+    if (tj == 0 && i < c) rqs[i] = rqa;
+  }
+#pragma unroll
+  for (int bb = 0; bb < 8; ++bb) {
+    const int j = tj + 16 * bb;
+    if (j < c) colp[ti * c + j] = colsum[bb];
   }
   tsum = wave_sum(tsum);
   if (lane == 0) red[wv] = tsum;
   __syncthreads();
   if (t == 0) dtemp_part[z] = (red[0] + red[1]) + (red[2] + red[3]);
   for (int j = t; j < c; j += 256) {
-    float acc = 0.f;
-    for (int i = 0; i < c; ++i) acc += sm[i * ld + j] * Pz[i * c + j] * temp;
-    rk[j] = acc;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s2 += colp[k * c + j];
+    rks[j] = s2;
   }
   __syncthreads();
   float* wq = wdq + (int64_t)z * c * 2 * c;
   float* wk = wdk + (int64_t)z * c * 2 * c;
-  for (int e = t; e < c * c; e += 256) {
-    const int i = e / c, j = e - i * c;
-    const float nq = nz[i], nk = nz[c + j];
-    const float g1 = temp * sm[i * ld + j] / (nq * nk);
-    wq[i * 2 * c + j] = g1;            // dq_i += g1 * k_j
-    wk[j * 2 * c + i] = g1;            // dk_j += g1 * q_i
-    // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
-    const float d1 = (i == j) ? ((nq > NORM_EPS) ? -rq[i] / (nq * nq) : 0.f) : 0.f;
-    const float nkj = nz[c + i];       // for the (i,i') slot of wk we need row index = i here
-    const float d2 = (i == j) ? ((nkj > NORM_EPS) ? -rk[i] / (nkj * nkj) : 0.f) : 0.f;
-    wq[i * 2 * c + c + j] = d1;
-    wk[i * 2 * c + c + j] = d2;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int i = ti + 16 * a;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      const int j = tj + 16 * bb;
+      if (i >= c || j >= c) continue;
+      const float nq = nz[i], nk = nz[c + j];
+      const float g1 = temp * acc[a][bb] / (nq * nk);
+      wq[i * 2 * c + j] = g1;            // dq_i += g1 * k_j
+      wk[j * 2 * c + i] = g1;            // dk_j += g1 * q_i
+      // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
+      const float nki = nz[c + i];
+      wq[i * 2 * c + c + j] = (i == j) ? ((nq > NORM_EPS) ? -rqs[i] / (nq * nq) : 0.f) : 0.f;
+      wk[i * 2 * c + c + j] = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
+    }
   }
 }
 
@@ -192,6 +256,8 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
   const size_t lds = (size_t)c * ld * sizeof(float);
+  if (lds > 64 * 1024)
+    MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(st, K_ATTN_FOLD, 4.0 * B * (3.0 * C * c + 2.0 * C * C), 2.0 * B * C * (double)c * C);
   hipLaunchKernelGGL(attn_fold_kernel, dim3(B * heads), dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, C, heads,
                      ld);
@@ -205,7 +271,9 @@ int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
-  const size_t lds = (size_t)c * ld * sizeof(float);
+  const size_t lds = ((size_t)c * ld + 2 * ATT_RC * c + 16 * c + 2 * c + 4) * sizeof(float);
+  if (lds > 64 * 1024)
+    MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(st, K_ATTN_BWD_SMALL, 4.0 * B * (6.0 * C * c + 3.0 * C * C), 4.0 * B * C * (double)c * C);
   hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(256), lds, st, dM, A, P, nrm, temperature, wo, dwo_part,
                      dtemp_part, wdq, wdk, C, heads, ld);

@@ -45,13 +45,52 @@ template <int KS, int TW> struct DwGeom {
   static constexpr int LH = TH + 2 * P;
 };
 
+// 4 consecutive pixels (x..x+3) of plane cc at row y; out-of-image pixels read as 0.  vec_ok: W % 4 == 0 and
+// 16-byte aligned bases, so a 4-group that starts inside the row lies entirely inside it.
+template <typename T, int MODE>
+__device__ __forceinline__ void dw_fetch4(const DwArgs& a, int b, int cc, int y, int x, bool vec_ok, float* o) {
+  if (!(vec_ok && x >= 0 && x + 3 < a.W)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (x + j >= 0 && x + j < a.W) ? dw_fetch<T, MODE>(a, b, cc, y, x + j) : 0.f;
+    return;
+  }
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int64_t pix = (int64_t)y * a.W + x;
+  if (MODE == IN_PLAIN) {
+    Vec<T, 4>::ld((const T*)a.in + ((int64_t)b * a.Cc + cc) * HW + pix, o);
+  } else {
+    const int j = cc < a.hidden ? cc : cc - a.hidden;
+    float dg[4], y1[4];
+    Vec<T, 4>::ld((const T*)a.in + ((int64_t)b * a.hidden + j) * HW + pix, dg);
+    Vec<T, 4>::ld((const T*)a.gy + ((int64_t)b * a.Cc + j) * HW + pix, y1);
+    if (cc < a.hidden) {
+      float y2[4];
+      Vec<T, 4>::ld((const T*)a.gy + ((int64_t)b * a.Cc + j + a.hidden) * HW + pix, y2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = dg[e] * y2[e] * gelu_erf_grad(y1[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = dg[e] * gelu_erf(y1[e]);
+    }
+  }
+}
+
+// Stage the (TH+2P) x (TW+2P) input tile: the TW interior columns as 4-wide vector loads, the 2P halo columns scalar.
 template <typename T, int KS, int TW, int MODE>
-__device__ __forceinline__ void dw_stage(float* tile, const DwArgs& a, int b, int cc, int y0, int x0) {
+__device__ __forceinline__ void dw_stage(float* tile, const DwArgs& a, int b, int cc, int y0, int x0, bool vec_ok) {
   using G = DwGeom<KS, TW>;
-  constexpr int ROWW = TW + 2 * G::P;
-  constexpr int TOT = G::LH * ROWW;
-  for (int e = threadIdx.x; e < TOT; e += 256) {
-    const int r = e / ROWW, c = e - r * ROWW;
+  constexpr int VPR = TW / 4;  // vectors per row
+  for (int e = threadIdx.x; e < G::LH * VPR; e += 256) {
+    const int r = e / VPR, v = e - r * VPR;
+    const int gy = y0 - G::P + r, gx = x0 + 4 * v;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < a.H && gx < a.W) dw_fetch4<T, MODE>(a, b, cc, gy, gx, vec_ok, o);
+    float* d = tile + r * G::LW + G::P + 4 * v;
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+  }
+  for (int e = threadIdx.x; e < G::LH * 2 * G::P; e += 256) {
+    const int r = e / (2 * G::P), hcol = e - r * (2 * G::P);
+    const int c = hcol < G::P ? hcol : TW + hcol;  // left halo cols [0,P), right halo cols [TW+P, TW+2P)
     const int gy = y0 - G::P + r, gx = x0 - G::P + c;
     float v = 0.f;
     if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = dw_fetch<T, MODE>(a, b, cc, gy, gx);
@@ -106,8 +145,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
     wsm[threadIdx.x] = a.w[(int64_t)cc * KS * KS + threadIdx.x];
     if (GATE) wsm[KS * KS + threadIdx.x] = a.w[(int64_t)(cc + a.hidden) * KS * KS + threadIdx.x];
   }
-  dw_stage<T, KS, TW, MODE>(tile, a, b, cc, y0, x0);
-  if (GATE) dw_stage<T, KS, TW, MODE>(tile + G::LH * G::LW, a, b, cc + a.hidden, y0, x0);
+  dw_stage<T, KS, TW, MODE>(tile, a, b, cc, y0, x0, vec_ok);
+  if (GATE) dw_stage<T, KS, TW, MODE>(tile + G::LH * G::LW, a, b, cc + a.hidden, y0, x0, vec_ok);
   __syncthreads();
   const int64_t HW = (int64_t)a.H * a.W;
   float o1[4];
@@ -135,7 +174,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
 // grid (tiles, Cc); loops over the batch; block partial -> part[tile][Cc*KK | Cc].
 template <typename T, int KS, int TW, int MODE>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwArgs dya, const T* __restrict__ xin, float* __restrict__ part,
-                                                           int B) {
+                                                           int B, int vec_ok) {
   using G = DwGeom<KS, TW>;
   constexpr int KK = KS * KS;
   __shared__ float tile[G::LH * G::LW];
@@ -152,11 +191,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwArgs dya, const T* 
   for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
   for (int b = 0; b < B; ++b) {
     __syncthreads();
-    dw_stage<T, KS, TW, IN_PLAIN>(tile, xa, b, cc, y0, x0);
-    float d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      d[j] = (oy < dya.H && ox + j < dya.W) ? dw_fetch<T, MODE>(dya, b, cc, oy, ox + j) : 0.f;
+    dw_stage<T, KS, TW, IN_PLAIN>(tile, xa, b, cc, y0, x0, vec_ok);
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (oy < dya.H && ox < dya.W) dw_fetch4<T, MODE>(dya, b, cc, oy, ox, vec_ok, d);
     __syncthreads();
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
@@ -194,7 +231,7 @@ static int dw_launch(DwArgs a, int B, hipStream_t st) {
   const int th = 256 / (tw / 4);
   a.tiles_x = cdiv(a.W, tw);
   const int tiles = a.tiles_x * cdiv(a.H, th);
-  const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate);
+  const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate) && aligned16(a.in) && aligned16(a.gy);
   dim3 grid(tiles, GATE ? a.hidden : a.Cc, B), block(256);
   const double plane = (double)B * a.H * a.W * sizeof(T);
   const int kid = GATE ? K_DW_GATE_FWD : (FLIP ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_FWD);
@@ -216,12 +253,13 @@ static int dw_wgrad_launch(DwArgs dya, const void* xin, float* part, int B, int*
   const int tiles = dya.tiles_x * cdiv(dya.H, th);
   *tiles_out = tiles;
   dim3 grid(tiles, dya.Cc), block(256);
+  const int vec_ok = (dya.W % 4 == 0) && aligned16(dya.in) && aligned16(dya.gy) && aligned16(xin);
   const double plane = (double)B * dya.H * dya.W * sizeof(T);
   ProfScope ps(st, K_DW_WGRAD, (MODE == IN_GATE_BWD ? dya.hidden + 2.0 * dya.Cc : 2.0 * dya.Cc) * plane,
                2.0 * KS * KS * dya.Cc * (double)B * dya.H * dya.W);
-  if (tw == 64) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 64, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);
-  else if (tw == 32) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 32, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);
-  else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 16, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B);
+  if (tw == 64) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 64, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
+  else if (tw == 32) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 32, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
+  else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 16, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -179,13 +179,21 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   const int zo = blockIdx.y;
   const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
   const int Z = batch * groups;
-  float s = 0.f;
-  if (sum_batch) {
-    for (int sp = 0; sp < splits; ++sp)
-      for (int b = 0; b < batch; ++b) s += part[((int64_t)sp * Z + (int64_t)b * groups + zo) * per + e];
-  } else {
-    for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * Z + zo) * per + e];
+  // slices to add: (split, batch) pairs for a batch-summed output, else splits; 4 loads in flight, fixed order
+  const int nb = sum_batch ? batch : 1;
+  const int total = splits * nb;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  auto addr = [&](int q) -> int64_t {
+    const int sp = q / nb, b = q - sp * nb;
+    const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
+    return ((int64_t)sp * Z + zz) * per + e;
+  };
+  int q = 0;
+  for (; q + 3 < total; q += 4) {
+    s0 += part[addr(q)]; s1 += part[addr(q + 1)]; s2 += part[addr(q + 2)]; s3 += part[addr(q + 3)];
   }
+  for (; q < total; ++q) s0 += part[addr(q)];
+  const float s = (s0 + s1) + (s2 + s3);
   float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
   *o = (accumulate ? *o : 0.f) + s;
 }
@@ -202,7 +210,7 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
   g.tiles_b = cdiv(d->mb, tile);
   g.Z = d->batch * d->groups;
   const int64_t tiles = (int64_t)g.tiles_a * g.tiles_b * g.Z;
-  int64_t want = 1024 / (tiles > 0 ? tiles : 1);
+  int64_t want = 512 / (tiles > 0 ? tiles : 1);
   if (want < 1) want = 1;
   if (want > g.nchunks) want = g.nchunks;
   g.cps = cdiv(g.nchunks, want);

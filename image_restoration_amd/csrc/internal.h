@@ -3,6 +3,18 @@
 #include "common.h"
 
 namespace mi {
+// kernel-side view of mi_pw_desc (strides in elements)
+struct PwK {
+  const void* x1; int64_t x1_bs, x1_gs; int k1;
+  const void* x2; int64_t x2_bs, x2_gs; int k2;
+  const float* w; int64_t w_bs, w_gs, w_sm, w_sk;
+  const float* bias; int64_t bias_gs;
+  const void* r; int64_t r_bs, r_gs;
+  void* y; int64_t y_bs, y_gs;
+  int m; int64_t n; int groups; int vec_ok;
+};
+int pw_stream_try(const PwK& k, int batch, hipStream_t st, int* launched);
+
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
                      float* nrm, float* M, int B, int C, int heads, hipStream_t st);
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,

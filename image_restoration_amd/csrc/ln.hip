@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restri
 static void ln_bwd_grid(int B, int64_t N, int vec, int* tiles_img, int* tpb, int* gx) {
   const int tile = 64 * vec;
   *tiles_img = cdiv(N, tile);
-  int want = cdiv((int64_t)*tiles_img * B, 1024);
+  int want = cdiv((int64_t)*tiles_img * B, 512);
   if (want < 1) want = 1;
   *tpb = want;
   *gx = cdiv(*tiles_img, *tpb);

@@ -8,7 +8,7 @@
 // bf16 activations use v_mfma_f32_16x16x32_bf16, fp32 activations the exact v_mfma_f32_16x16x4_f32.
 #include <type_traits>
 
-#include "common.h"
+#include "internal.h"
 
 namespace mi {
 
@@ -16,15 +16,6 @@ constexpr int PW_TN = 64;  // pixels per workgroup tile
 constexpr int PW_KC = 32;  // k per staged chunk
 constexpr int PW_XS = 80;  // LDS row stride (elements) of the X chunk: conflict-free tr-reads / b32 reads
 
-struct PwK {
-  const void* x1; int64_t x1_bs, x1_gs; int k1;
-  const void* x2; int64_t x2_bs, x2_gs; int k2;
-  const float* w; int64_t w_bs, w_gs, w_sm, w_sk;
-  const float* bias; int64_t bias_gs;
-  const void* r; int64_t r_bs, r_gs;
-  void* y; int64_t y_bs, y_gs;
-  int m; int64_t n; int groups; int vec_ok;
-};
 
 template <typename T, int TM, bool WT> struct PwLds {
   static constexpr int WS_ROW = std::is_same<T, float>::value ? 34 : 40;  // [m][k] row stride
@@ -267,6 +258,11 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* stream) {
   k.vec_ok = ok ? 1 : 0;
   const bool wt = (d->w_sk != 1);  // m-contiguous weights: stage [k][m]
   hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == MI_BF16) {  // HBM-bound shapes: weights resident in LDS, tiles streamed (pw_stream.hip)
+    int launched = 0;
+    MI_TRY(pw_stream_try(k, d->batch, st, &launched));
+    if (launched) return MI_OK;
+  }
   if (d->dtype == MI_F32) return wt ? pw_launch<float, true>(k, d->batch, st) : pw_launch<float, false>(k, d->batch, st);
   return wt ? pw_launch<bf16, true>(k, d->batch, st) : pw_launch<bf16, false>(k, d->batch, st);
 }

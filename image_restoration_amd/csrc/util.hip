@@ -47,16 +47,26 @@ ProfScope::~ProfScope() {
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int64_t rows, int64_t cols, int64_t ld, int accumulate,
                                                           float scale) {
-  __shared__ float sm[4][64];
-  const int cx = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
-  float acc = 0.f;
-  if (c < cols)
-    for (int64_t r = ph; r < rows; r += 4) acc += part[r * ld + c];
-  sm[ph][cx] = acc;
+  __shared__ float sm[8][32];
+  const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + cx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int64_t r = ph;
+    for (; r + 24 < rows; r += 32) {  // four loads in flight per thread; fixed order -> reproducible
+      a0 += part[r * ld + c];
+      a1 += part[(r + 8) * ld + c];
+      a2 += part[(r + 16) * ld + c];
+      a3 += part[(r + 24) * ld + c];
+    }
+    for (; r < rows; r += 8) a0 += part[r * ld + c];
+  }
+  sm[ph][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (ph == 0 && c < cols) {
-    const float t = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][cx];
     out[c] = (accumulate ? out[c] : 0.f) + scale * t;
   }
 }
@@ -65,7 +75,7 @@ int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols
                        float scale, hipStream_t st) {
   if (cols <= 0) return MI_OK;
   ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + 1) * cols * 4, (double)rows * cols);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, part, out, rows, cols, part_ld,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, st, part, out, rows, cols, part_ld,
                      accumulate, scale);
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -211,3 +211,63 @@ def test_l1_loss(dtype):
     ref = (a.double() - b.double()).abs().mean()
     assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
     assert rel(da, torch.sign(a.double() - b.double()) / a.numel()) < 1e-2
+
+
+# --------------------------------------------------------------------------- streaming pointwise GEMM (bf16)
+def _pw_raw(x1, x2, w, bias, res, M, groups, w_per_image, transposed):
+    """Full mi_pw_desc call: x [B, groups*K, H, W] split head-major into groups; w [(B,) groups, M, K] or its transpose."""
+    import ctypes as C
+    from image_restoration_amd import _lib as L, ops as o
+    B, CK, H, W = x1.shape
+    N = H * W
+    K1 = CK // groups
+    K2 = 0 if x2 is None else x2.shape[1] // groups
+    K = K1 + K2
+    y = torch.empty((B, groups * M, H, W), dtype=x1.dtype, device=x1.device)
+    d = L.PwDesc()
+    d.x1, d.x1_bs, d.x1_gs, d.k1 = x1.data_ptr(), CK * N, K1 * N, K1
+    if x2 is not None:
+        d.x2, d.x2_bs, d.x2_gs, d.k2 = x2.data_ptr(), x2.shape[1] * N, K2 * N, K2
+    d.w = w.data_ptr()
+    d.w_gs = M * K
+    d.w_bs = groups * M * K if w_per_image else 0
+    d.w_sm, d.w_sk = (1, M) if transposed else (K, 1)
+    if bias is not None:
+        d.bias, d.bias_gs = bias.data_ptr(), M
+    if res is not None:
+        d.r, d.r_bs, d.r_gs = res.data_ptr(), groups * M * N, M * N
+    d.y, d.y_bs, d.y_gs = y.data_ptr(), groups * M * N, M * N
+    d.m, d.n, d.batch, d.groups, d.dtype = M, N, B, groups, o._dt(x1)
+    L.check(L.lib().mi_pw_gemm(C.byref(d), o._stream()), "pw_gemm")
+    return y
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("M,K1,K2,groups,per_image,hw", [
+    (144, 48, 0, 1, False, (16, 64)), (254, 48, 0, 1, False, (16, 64)), (48, 127, 0, 1, False, (16, 64)),
+    (48, 144, 0, 1, False, (8, 64)), (127, 48, 0, 1, False, (8, 64)), (48, 254, 0, 1, False, (8, 64)),
+    (288, 96, 0, 1, False, (8, 64)), (96, 255, 0, 1, False, (8, 64)), (96, 288, 0, 1, False, (8, 64)),
+    (96, 510, 0, 1, False, (8, 64)), (510, 96, 0, 1, False, (8, 64)), (48, 48, 48, 2, True, (16, 64)),
+    (96, 96, 96, 1, True, (8, 72)), (37, 20, 13, 3, True, (5, 7)), (48, 48, 0, 1, True, (9, 11))])
+def test_pw_stream_exact_on_integers(monkeypatch, transposed, M, K1, K2, groups, per_image, hw):
+    """The LDS-resident-weight streaming kernel (bf16): forced on, every k-step count (K 48..510, two X passes),
+    both weight orientations, two K-panels, head groups, per-image weights, ragged pixel counts.  Integer data: exact
+    up to the final bf16 rounding of the store."""
+    monkeypatch.setenv("MI_PW_FORCE_STREAM", "1")
+    B = 2
+    K = K1 + K2
+    x1 = ints((B, groups * K1, *hw), 91).bfloat16()
+    x2 = ints((B, groups * K2, *hw), 92).bfloat16() if K2 else None
+    wshape = (B if per_image else 1, groups, M, K)
+    w = ints(wshape, 93, -2, 3)
+    bias = ints((groups, M), 94)
+    res = ints((B, groups * M, *hw), 95).bfloat16()
+    xs = x1.float().reshape(B, groups, K1, -1)
+    if K2:
+        xs = torch.cat([xs, x2.float().reshape(B, groups, K2, -1)], 2)
+    ref = torch.einsum("bgmk,bgkn->bgmn", w.expand(B, -1, -1, -1), xs) + bias[None, :, :, None]
+    ref = (ref.reshape(B, groups * M, *hw) + res.float()).bfloat16().float()
+    warg = w.transpose(-1, -2).contiguous() if transposed else w
+    y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), bias.to(DEV), res.to(DEV), M, groups,
+                per_image, transposed)
+    assert torch.equal(y.float().cpu(), ref), f"max diff {(y.float().cpu() - ref).abs().max()}"
