@@ -148,10 +148,19 @@ template <> struct Vec<bf16, 8> {
   }
 };
 
+// Wave-wide sum on the VALU (DPP row shifts + row broadcasts; no LDS-pipe ds_bpermute): lane 63 ends up with the
+// total, which is returned wave-uniform.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define MI_DPP_ADD(ctrl, rmask)                                                                                   \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  MI_DPP_ADD(0x111, 0xf);  // row_shr:1
+  MI_DPP_ADD(0x112, 0xf);  // row_shr:2
+  MI_DPP_ADD(0x114, 0xf);  // row_shr:4
+  MI_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of every 16-lane row holds the row sum
+  MI_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  MI_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef MI_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -182,7 +191,8 @@ struct ProfScope {
 };
 
 // generic small kernels implemented in util.hip, used by several modules
+constexpr int REDUCE_GROUPS = 32;
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld,
-                       int accumulate, float scale, hipStream_t st);
+                       int accumulate, float scale, hipStream_t st, float* tmp = nullptr);
 
 }  // namespace mi

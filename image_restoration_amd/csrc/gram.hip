@@ -170,32 +170,42 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
 }
 
 // out[zo][i*ld + j] (+)= sum_{split} sum_{b if sum_batch} part[split][b*groups+g][i][j]
+// 256 threads = 16 consecutive elements x 16 slice-phases; each thread walks its slices 4 at a time (loads in flight),
+// phases are combined through LDS in a fixed order (reproducible).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int splits, int batch, int groups, int ma, int mb, int64_t out_ld,
                                                           int64_t out_zs, int sum_batch, int accumulate) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sm[16][17];
+  const int ex = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + ex;
   const int64_t per = (int64_t)ma * mb;
-  if (e >= per) return;
   const int zo = blockIdx.y;
-  const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
   const int Z = batch * groups;
-  // slices to add: (split, batch) pairs for a batch-summed output, else splits; 4 loads in flight, fixed order
   const int nb = sum_batch ? batch : 1;
   const int total = splits * nb;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  auto addr = [&](int q) -> int64_t {
-    const int sp = q / nb, b = q - sp * nb;
-    const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
-    return ((int64_t)sp * Z + zz) * per + e;
-  };
-  int q = 0;
-  for (; q + 3 < total; q += 4) {
-    s0 += part[addr(q)]; s1 += part[addr(q + 1)]; s2 += part[addr(q + 2)]; s3 += part[addr(q + 3)];
+  if (e < per) {
+    auto addr = [&](int q) -> int64_t {
+      const int sp = q / nb, b = q - sp * nb;
+      const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
+      return ((int64_t)sp * Z + zz) * per + e;
+    };
+    int q = ph;
+    for (; q + 48 < total; q += 64) {
+      s0 += part[addr(q)]; s1 += part[addr(q + 16)]; s2 += part[addr(q + 32)]; s3 += part[addr(q + 48)];
+    }
+    for (; q < total; q += 16) s0 += part[addr(q)];
   }
-  for (; q < total; ++q) s0 += part[addr(q)];
-  const float s = (s0 + s1) + (s2 + s3);
-  float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
-  *o = (accumulate ? *o : 0.f) + s;
+  sm[ph][ex] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && e < per) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k][ex];
+    const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
+    float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
+    *o = (accumulate ? *o : 0.f) + s;
+  }
 }
 
 struct GramPlan { int F, kc, nchunks, tiles_a, tiles_b, splits, cps, Z; size_t part_bytes, ss_bytes; };
@@ -277,7 +287,7 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
   const int zo = d->sum_batch ? d->groups : g.Z;
   const int64_t per = (int64_t)d->ma * d->mb;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 256), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
                      d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
   MI_LAUNCH_CHECK();
   if (ss) {

@@ -6,10 +6,9 @@
 
 namespace mi {
 
-constexpr int LN_WAVES = 8;
 constexpr float LN_EPS = 1e-5f;
 
-template <typename T, int CPT, int VEC, bool WITH_BIAS>
+template <typename T, int LN_WAVES, int CPT, int VEC, bool WITH_BIAS>
 __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ b, T* __restrict__ y,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -20,8 +19,9 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restri
   const int64_t n = (int64_t)blockIdx.x * TILE + lane * VEC;
   const bool valid = n < N;  // VEC>1 is only used when N % VEC == 0
   const int64_t boff = (int64_t)blockIdx.y * C * N;
-  const T* xb = x + boff;
+  const T* xb = x + boff;  // wave-uniform bases; per-channel addresses are 32-bit offsets (host checks C*N < 2^31)
   T* yb = y + boff;
+  const unsigned N32 = (unsigned)N, n32 = (unsigned)n;
 
   float v[CPT][VEC];
   float s[VEC];
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restri
   for (int i = 0; i < CPT; ++i) {
     const int c = wv + LN_WAVES * i;
     if (c < C && valid) {
-      Vec<T, VEC>::ld(xb + (int64_t)c * N + n, v[i]);
+      Vec<T, VEC>::ld(xb + ((unsigned)c * N32 + n32), v[i]);
     } else {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restri
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
         o[j] = WITH_BIAS ? (v[i][j] - mu[j]) * rs[j] * wc + bc : v[i][j] * rs[j] * wc;
-      Vec<T, VEC>::st(yb + (int64_t)c * N + n, o);
+      Vec<T, VEC>::st(yb + ((unsigned)c * N32 + n32), o);
     }
   }
   if (wv == 0 && mean_out) {
@@ -94,65 +94,72 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restri
 
 // Backward.  WithBias:  xh=(x-mu)r, g=dy*w, dx = r*(g - mean_c(g) - xh*mean_c(g*xh)), dw+=dy*xh, db+=dy.
 // BiasFree (y = x*r*w): g=dy*w, dx = r*g - r^3*(x-mu)*mean_c(g*x), dw += dy*x*r.
-template <typename T, int CPT, int VEC, bool WITH_BIAS>
+// REREAD (wide C): the per-pixel channel sums are taken in a first sweep and dy,x are read again (from L2) for the
+// second, so a thread holds only its 2*CPT partial sums instead of 2*CPT*VEC staged values as well.
+template <typename T, int LN_WAVES, int CPT, int VEC, bool WITH_BIAS, bool REREAD>
 __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                 const float* __restrict__ w, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const T* __restrict__ dres,
                                                                 T* __restrict__ dx, float* __restrict__ part, int C, int64_t N,
                                                                 int tiles_per_block, int tiles_per_image) {
   constexpr int TILE = 64 * VEC;
+  constexpr int KEEP = REREAD ? 1 : CPT;
   __shared__ float red1[LN_WAVES][TILE];
   __shared__ float red2[LN_WAVES][TILE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t boff = (int64_t)blockIdx.y * C * N;
+  const T* dyb = dy + boff;  // wave-uniform bases + 32-bit element offsets keep the address state out of the VGPRs
+  const T* xb = x + boff;
+  const T* rb = dres ? dres + boff : nullptr;
+  T* dxb = dx + boff;
+  const unsigned N32 = (unsigned)N;
   const float invC = 1.0f / (float)C;
-  float aw[CPT], ab[CPT], wreg[CPT];
+  float aw[CPT], ab[CPT];
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    aw[i] = 0.f; ab[i] = 0.f;
-    const int c = wv + LN_WAVES * i;
-    wreg[i] = c < C ? w[c] : 0.f;
-  }
-  const int t0 = blockIdx.x * tiles_per_block;
-  for (int t = t0; t < t0 + tiles_per_block && t < tiles_per_image; ++t) {
-    const int64_t n = (int64_t)t * TILE + lane * VEC;
+  for (int i = 0; i < CPT; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+  (void)tiles_per_block; (void)tiles_per_image;
+  {  // one pixel tile per workgroup: a tile loop makes LICM hoist every per-channel address out of it (spills)
+    const int64_t n = (int64_t)blockIdx.x * TILE + lane * VEC;
     const bool valid = n < N;
+    const unsigned n32 = (unsigned)n;
     float mu[VEC], rs[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = valid ? mean[(int64_t)blockIdx.y * N + n + j] : 0.f;
       rs[j] = valid ? rstd[(int64_t)blockIdx.y * N + n + j] : 0.f;
     }
-    float g[CPT][VEC], xv[CPT][VEC];
+    float g[KEEP][VEC], xv[KEEP][VEC];
     float s1[VEC], s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // sweep 1: channel sums (and, unless REREAD, the staged g = dy*w and xh / x-mu)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = wv + LN_WAVES * i;
+      const float wc = c < C ? w[c] : 0.f;
+      float gi[VEC], xi[VEC];
       if (c < C && valid) {
-        Vec<T, VEC>::ld(dy + boff + (int64_t)c * N + n, g[i]);
-        Vec<T, VEC>::ld(x + boff + (int64_t)c * N + n, xv[i]);
+        Vec<T, VEC>::ld(dyb + ((unsigned)c * N32 + n32), gi);
+        Vec<T, VEC>::ld(xb + ((unsigned)c * N32 + n32), xi);
       } else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { g[i][j] = 0.f; xv[i][j] = 0.f; }
+        for (int j = 0; j < VEC; ++j) { gi[j] = 0.f; xi[j] = 0.f; }
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const float dyv = g[i][j];
+        const float dyv = gi[j];
+        const float gw = dyv * wc;
         if (WITH_BIAS) {
-          const float xh = (xv[i][j] - mu[j]) * rs[j];
-          aw[i] += dyv * xh; ab[i] += dyv;
-          const float gw = dyv * wreg[i];
+          const float xh = (xi[j] - mu[j]) * rs[j];
           s1[j] += gw; s2[j] += gw * xh;
-          g[i][j] = gw; xv[i][j] = xh;
+          if (!REREAD) { aw[i] += dyv * xh; ab[i] += dyv; g[i][j] = gw; xv[i][j] = xh; }
         } else {
-          aw[i] += dyv * xv[i][j] * rs[j];
-          const float gw = dyv * wreg[i];
-          s2[j] += gw * xv[i][j];
-          g[i][j] = gw; xv[i][j] = xv[i][j] - mu[j];
+          s2[j] += gw * xi[j];
+          if (!REREAD) { aw[i] += dyv * xi[j] * rs[j]; g[i][j] = gw; xv[i][j] = xi[j] - mu[j]; }
         }
       }
+      // bound the live ranges: without this the scheduler hoists every load of the unrolled sweep to the top
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { red1[wv][lane * VEC + j] = s1[j]; red2[wv][lane * VEC + j] = s2[j]; }
@@ -166,26 +173,47 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restri
       m1[j] = a * invC; m2[j] = bsum * invC;
     }
     __syncthreads();
-    if (valid) {
+    // sweep 2: dx (+dres) and, with REREAD, the weight/bias partial sums
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int c = wv + LN_WAVES * i;
-        if (c < C) {
-          float o[VEC];
+    for (int i = 0; i < CPT; ++i) {
+      const int c = wv + LN_WAVES * i;
+      if (c < C && valid) {
+        float gw[VEC], xq[VEC];
+        if (REREAD) {
+          const float wc = w[c];
+          float gi[VEC], xi[VEC];
+          Vec<T, VEC>::ld(dyb + ((unsigned)c * N32 + n32), gi);
+          Vec<T, VEC>::ld(xb + ((unsigned)c * N32 + n32), xi);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            if (WITH_BIAS) o[j] = rs[j] * (g[i][j] - m1[j] - xv[i][j] * m2[j]);
-            else o[j] = rs[j] * g[i][j] - rs[j] * rs[j] * rs[j] * xv[i][j] * m2[j];
+            gw[j] = gi[j] * wc;
+            if (WITH_BIAS) {
+              xq[j] = (xi[j] - mu[j]) * rs[j];
+              aw[i] += gi[j] * xq[j]; ab[i] += gi[j];
+            } else {
+              xq[j] = xi[j] - mu[j];
+              aw[i] += gi[j] * xi[j] * rs[j];
+            }
           }
-          if (dres) {
-            float r[VEC];
-            Vec<T, VEC>::ld(dres + boff + (int64_t)c * N + n, r);
+        } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) o[j] += r[j];
-          }
-          Vec<T, VEC>::st(dx + boff + (int64_t)c * N + n, o);
+          for (int j = 0; j < VEC; ++j) { gw[j] = g[REREAD ? 0 : i][j]; xq[j] = xv[REREAD ? 0 : i][j]; }
         }
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (WITH_BIAS) o[j] = rs[j] * (gw[j] - m1[j] - xq[j] * m2[j]);
+          else o[j] = rs[j] * gw[j] - rs[j] * rs[j] * rs[j] * xq[j] * m2[j];
+        }
+        if (rb) {
+          float r[VEC];
+          Vec<T, VEC>::ld(rb + ((unsigned)c * N32 + n32), r);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] += r[j];
+        }
+        Vec<T, VEC>::st(dxb + ((unsigned)c * N32 + n32), o);
       }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
   // every channel is owned by exactly one wave: reduce over its 64 lanes, lane 0 writes the block partial
@@ -202,25 +230,26 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restri
 static void ln_bwd_grid(int B, int64_t N, int vec, int* tiles_img, int* tpb, int* gx) {
   const int tile = 64 * vec;
   *tiles_img = cdiv(N, tile);
-  int want = cdiv((int64_t)*tiles_img * B, 512);
-  if (want < 1) want = 1;
-  *tpb = want;
+  (void)B;
+  *tpb = 1;
   *gx = cdiv(*tiles_img, *tpb);
 }
 
+// (waves, channels per thread): C <= 8*{2,6,12,24} with 8 waves, C <= 16*24 = 384 with 16 waves, 16*48 = 768 beyond.
 template <typename T, int VEC, bool WB>
 static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, float* mean, float* rstd, int B, int C,
                            int64_t N, hipStream_t st) {
-  dim3 grid(cdiv(N, 64 * VEC), B), block(64 * LN_WAVES);
+  dim3 grid(cdiv(N, 64 * VEC), B);
   ProfScope ps(st, K_LN_FWD, 2.0 * B * C * N * sizeof(T) + (mean ? 8.0 * B * N : 0.0), 8.0 * B * C * N);
-#define LN_FWD_CASE(CPT)                                                                                   \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, x, w, b, y, mean, rstd, C, N)
-  if (C <= 16) LN_FWD_CASE(2);
-  else if (C <= 48) LN_FWD_CASE(6);
-  else if (C <= 96) LN_FWD_CASE(12);
-  else if (C <= 192) LN_FWD_CASE(24);
-  else if (C <= 384) LN_FWD_CASE(48);
-  else { set_error("ln_fwd: C=%d > 384 unsupported", C); return MI_ERR_ARG; }
+#define LN_FWD_CASE(WV, CPT)                                                                                         \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, WV, CPT, VEC, WB>), grid, dim3(64 * WV), 0, st, x, w, b, y, mean, rstd, C, N)
+  if (C <= 16) LN_FWD_CASE(8, 2);
+  else if (C <= 48) LN_FWD_CASE(8, 6);
+  else if (C <= 96) LN_FWD_CASE(8, 12);
+  else if (C <= 192) LN_FWD_CASE(8, 24);
+  else if (C <= 384) LN_FWD_CASE(16, 24);
+  else if (C <= 768) LN_FWD_CASE(16, 48);
+  else { set_error("ln_fwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
 #undef LN_FWD_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -229,24 +258,28 @@ static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, flo
 template <typename T, int VEC, bool WB>
 static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float* mean, const float* rstd, const T* dres,
                            T* dx, float* part, int B, int C, int64_t N, int gx, int tpb, int tiles_img, hipStream_t st) {
-  dim3 grid(gx, B), block(64 * LN_WAVES);
+  dim3 grid(gx, B);
   ProfScope ps(st, K_LN_BWD, (dres ? 4.0 : 3.0) * B * C * N * sizeof(T) + 8.0 * B * N, 16.0 * B * C * N);
-#define LN_BWD_CASE(CPT)                                                                                     \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, CPT, VEC, WB>), grid, block, 0, st, dy, x, w, mean, rstd, dres, dx, part, C, N, \
-                     tpb, tiles_img)
-  if (C <= 16) LN_BWD_CASE(2);
-  else if (C <= 48) LN_BWD_CASE(6);
-  else if (C <= 96) LN_BWD_CASE(12);
-  else if (C <= 192) LN_BWD_CASE(24);
-  else if (C <= 384) LN_BWD_CASE(48);
-  else { set_error("ln_bwd: C=%d > 384 unsupported", C); return MI_ERR_ARG; }
+#define LN_BWD_CASE(WV, CPT)                                                                                           \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, WV, CPT, VEC, WB, (CPT >= 24)>), grid, dim3(64 * WV), 0, st, dy, x, w, mean, rstd, dres, dx, part, \
+                     C, N, tpb, tiles_img)
+  if (C <= 16) LN_BWD_CASE(8, 2);
+  else if (C <= 48) LN_BWD_CASE(8, 6);
+  else if (C <= 96) LN_BWD_CASE(8, 12);
+  else if (C <= 192) LN_BWD_CASE(8, 24);
+  else if (C <= 384) LN_BWD_CASE(16, 24);
+  else if (C <= 768) LN_BWD_CASE(16, 48);
+  else { set_error("ln_bwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
 #undef LN_BWD_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
 
-static int ln_vec(int dtype, int64_t N, const void* a, const void* b) {
+// bf16 rows are read two pixels per lane when that is aligned; wide-C backward keeps one pixel per lane so that its
+// per-thread state (2*CPT*VEC values + 2*CPT partial sums) stays inside the 128-VGPR budget of a 16-wave workgroup.
+static int ln_vec(int dtype, int64_t N, const void* a, const void* b, int C = 0, bool bwd = false) {
   if (dtype != MI_BF16) return 1;
+  if (bwd && C > 192) return 1;
   const bool ok = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3u) == 0;
   return ok ? 2 : 1;
 }
@@ -259,6 +292,7 @@ extern "C" int mi_ln_fwd(const void* x, const float* w, const float* b, void* y,
                          int64_t N, int with_bias, int dtype, void* stream) {
   MI_CHECK_ARG(x && w && y, "ln_fwd: null pointer");
   MI_CHECK_ARG(B > 0 && C > 0 && N > 0, "ln_fwd: bad shape B=%d C=%d N=%lld", B, C, (long long)N);
+  MI_CHECK_ARG((int64_t)C * N < (1ll << 31), "ln_fwd: C*H*W must be below 2^31");
   MI_CHECK_ARG(!with_bias || b, "ln_fwd: with_bias needs b");
   MI_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or both NULL");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_fwd: bad dtype %d", dtype);
@@ -280,7 +314,7 @@ extern "C" size_t mi_ln_bwd_workspace(int B, int C, int64_t N) {
   ln_bwd_grid(B, N, 1, &tiles_img, &tpb, &gx1);
   ln_bwd_grid(B, N, 2, &tiles_img, &tpb, &gx2);
   const int gx = gx1 > gx2 ? gx1 : gx2;
-  return align_up((size_t)gx * B * 2 * C * sizeof(float), 256);
+  return align_up(((size_t)gx * B + REDUCE_GROUPS) * 2 * C * sizeof(float), 256);
 }
 
 extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -288,10 +322,11 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
                          int accumulate, int dtype, void* ws, void* stream) {
   MI_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && ws, "ln_bwd: null pointer");
   MI_CHECK_ARG(B > 0 && C > 0 && N > 0, "ln_bwd: bad shape");
+  MI_CHECK_ARG((int64_t)C * N < (1ll << 31), "ln_bwd: C*H*W must be below 2^31");
   MI_CHECK_ARG(!with_bias || db, "ln_bwd: with_bias needs db");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  int vec = ln_vec(dtype, N, dy, x);
+  int vec = ln_vec(dtype, N, dy, x, C, true);
   if (vec == 2 && ln_vec(dtype, N, dx, dres) != 2) vec = 1;
   int tiles_img, tpb, gx;
   ln_bwd_grid(B, N, vec, &tiles_img, &tpb, &gx);
@@ -315,7 +350,8 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
   }
   if (rc != MI_OK) return rc;
   const int64_t rows = (int64_t)gx * B;
-  MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st));
-  if (with_bias) MI_TRY(launch_reduce_rows(part + C, db, rows, C, 2 * C, accumulate, 1.0f, st));
+  float* tmp = part + rows * 2 * C;  // two-stage scratch: [REDUCE_GROUPS][C] for dw, then the same for db
+  MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st, tmp));
+  if (with_bias) MI_TRY(launch_reduce_rows(part + C, db, rows, C, 2 * C, accumulate, 1.0f, st, tmp + (size_t)REDUCE_GROUPS * C));
   return MI_OK;
 }

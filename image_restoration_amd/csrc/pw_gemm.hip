@@ -36,8 +36,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int TM = 64 * MF;
   using L = PwLds<T, TM, WT>;
-  __shared__ __attribute__((aligned(16))) T Xs[L::X_ELEMS];
-  __shared__ __attribute__((aligned(16))) T Ws[L::W_ELEMS];
+  constexpr int STAGE_BYTES = (L::X_ELEMS + L::W_ELEMS) * (int)sizeof(T);
+  constexpr int SLAB_BYTES = 4 * 16 * (PW_TN + 4) * (int)sizeof(float);  // epilogue: 4 waves x 16 rows x fp32
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES];
+  T* const Xs = reinterpret_cast<T*>(lds_raw);
+  T* const Ws = Xs + L::X_ELEMS;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -182,35 +185,55 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
     }
   }
 
-  // ---- epilogue: lane holds pixels n0+16nf+4g+{0..3} of output channel m0+mw+16mf+li ----
+  // ---- epilogue: lane holds pixels n0+16nf+4g+{0..3} of output channel m0+mw+16mf+li.  Stored from the
+  // accumulator that is 8 bytes per lane scattered over 16 rows; the rows are therefore staged through LDS (one
+  // 16-row slab per wave at a time) and written as whole 128-byte row segments, 16 bytes per lane.
   T* yz = (T*)p.y + zb * p.y_bs + zg * p.y_gs;
   const T* rz = p.r ? (const T*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
   const float* bz = p.bias ? p.bias + zg * p.bias_gs : nullptr;
+  constexpr int EPV = F32 ? 4 : 8;        // pixels per 16-byte vector of the output type
+  constexpr int OS = PW_TN + 4;           // fp32 slab row stride (floats): 272 bytes
+  constexpr int LPR = PW_TN / EPV;        // lanes per row on the way out
+  constexpr int RPI = 64 / LPR;           // rows per store instruction
+  float* slab = reinterpret_cast<float*>(lds_raw) + wv * 16 * OS;  // kept in fp32: the only rounding is the final store
+  __syncthreads();                        // every wave is done reading the last chunk
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
-    const int m = m0 + mw + 16 * mf + li;
-    if (m >= p.m) continue;
-    const float bv = bz ? bz[m] : 0.f;
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      const int64_t n = n0 + 16 * nf + 4 * g;
-      if (n >= p.n) continue;
-      float o[4] = {acc[nf][mf][0] + bv, acc[nf][mf][1] + bv, acc[nf][mf][2] + bv, acc[nf][mf][3] + bv};
-      const int64_t off = (int64_t)m * p.n + n;
-      if (p.vec_ok) {
-        if (rz) {
-          float rr[4];
-          Vec<T, 4>::ld(rz + off, rr);
+      float o[4] = {acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]};
+      Vec<float, 4>::st(&slab[li * OS + 16 * nf + 4 * g], o);
+    }
+    __syncthreads();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += rr[j];
+    for (int it = 0; it < 16 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR, col = (lane % LPR) * EPV;
+      const int m = m0 + mw + 16 * mf + row;
+      const int64_t n = n0 + col;
+      if (m < p.m && n < p.n) {
+        float o[EPV];
+#pragma unroll
+        for (int v = 0; v < EPV / 4; ++v) Vec<float, 4>::ld(&slab[row * OS + col + 4 * v], o + 4 * v);
+        const float bv = bz ? bz[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) o[j] += bv;
+        const int64_t off = (int64_t)m * p.n + n;
+        if (p.vec_ok) {
+          if (rz) {
+            float rr[EPV];
+            Vec<T, EPV>::ld(rz + off, rr);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) o[j] += rr[j];
+          }
+          Vec<T, EPV>::st(yz + off, o);
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPV; ++j)
+            if (n + j < p.n) st1(yz + off + j, o[j] + (rz ? ld1(rz + off + j) : 0.f));
         }
-        Vec<T, 4>::st(yz + off, o);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.n) st1(yz + off + j, o[j] + (rz ? ld1(rz + off + j) : 0.f));
       }
     }
+    __syncthreads();
   }
 }
 

@@ -20,6 +20,7 @@ constexpr int PS_MF = 4;        // output-channel fragments per sweep step
 struct PwS {
   PwK k;
   int tiles_per_block, n_tiles, ksteps, kpad, mpad, w_stride, x_rows, passes;
+  int nt;  // 64-pixel sub-tiles loaded together (one "super-tile"): keeps nt * K * 128 bytes of loads in flight
 };
 
 __device__ __forceinline__ s16x4 ps_tr(const void* p) {
@@ -73,14 +74,16 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwS s) {
 
   // ---- X staging: rows (pass*256 + r) of the tile, 16-byte vectors, thread -> (row = vid>>3, col = (vid&7)*8) ----
   u32x4 xreg[8];
-  const int xv = s.x_rows / 32;  // vectors per thread per pass (<= 8)
+  const int xv = s.x_rows * s.nt / 32;  // vectors per thread per pass (<= 8)
+  const int rows8 = s.x_rows * 8;       // vectors per sub-tile
   auto load_x = [&](int64_t n0, int pass) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < xv) {
         const int vid = t + 256 * i;
-        const int k = pass * PS_XROWS + (vid >> 3);
-        const int64_t n = n0 + (vid & 7) * 8;
+        const int sub = vid / rows8, v2 = vid - sub * rows8;
+        const int k = pass * PS_XROWS + (v2 >> 3);
+        const int64_t n = n0 + sub * PS_TN + (v2 & 7) * 8;
         const bf16* row = nullptr;
         if (k < p.k1) row = x1 + (int64_t)k * p.n;
         else if (k < ktot) row = x2 + (int64_t)(k - p.k1) * p.n;
@@ -99,21 +102,21 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwS s) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < xv) {
-        const int vid = t + 256 * i;
+        const int vid = t + 256 * i;  // sub-tile-major image: [nt][x_rows][PS_XS]
         *reinterpret_cast<u32x4*>(&Xs[(vid >> 3) * PS_XS + (vid & 7) * 8]) = xreg[i];
       }
     }
   };
 
   s16x8 afr[KS_MAX];
-  auto read_a = [&](int pass) {  // this wave's X^T fragments (pixel group wv) for the k-steps of one pass
+  auto read_a = [&](int pass, const bf16* Xt) {  // this wave's X^T fragments (pixel group wv), k-steps of one pass
     s16x4 lo[8], hi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ks = pass * 8 + j;
       if (j < KS_MAX && ks < s.ksteps) {
-        lo[j] = ps_tr(&Xs[(32 * j + 4 * g + q) * PS_XS + 16 * wv + 4 * pp]);
-        hi[j] = ps_tr(&Xs[(32 * j + 16 + 4 * g + q) * PS_XS + 16 * wv + 4 * pp]);
+        lo[j] = ps_tr(&Xt[(32 * j + 4 * g + q) * PS_XS + 16 * wv + 4 * pp]);
+        hi[j] = ps_tr(&Xt[(32 * j + 16 + 4 * g + q) * PS_XS + 16 * wv + 4 * pp]);
       } else {
         lo[j] = (s16x4){0, 0, 0, 0};
         hi[j] = (s16x4){0, 0, 0, 0};
@@ -131,26 +134,32 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwS s) {
     }
   };
 
+  // tiles are counted in super-tiles of nt*64 pixels
   const int tile0 = blockIdx.x * s.tiles_per_block;
   int tile_end = tile0 + s.tiles_per_block;
   if (tile_end > s.n_tiles) tile_end = s.n_tiles;
-  if (tile0 < tile_end) load_x((int64_t)tile0 * PS_TN, 0);
+  const int64_t super_px = (int64_t)s.nt * PS_TN;
+  if (tile0 < tile_end) load_x((int64_t)tile0 * super_px, 0);
   const int mfrags = s.mpad / 16;
 
   for (int tile = tile0; tile < tile_end; ++tile) {
-    const int64_t n0 = (int64_t)tile * PS_TN;
-    __syncthreads();  // W ready (first tile) / everyone done with the previous X tile
+    const int64_t ns = (int64_t)tile * super_px;
+    __syncthreads();  // W ready (first tile) / everyone done with the previous X image
     write_x();
     __syncthreads();
-    read_a(0);
-    if (KS_MAX > 8 && s.passes > 1) {
+    if (s.passes == 1 && tile + 1 < tile_end) load_x(ns + super_px, 0);  // next super-tile flies during the multiply
+   for (int sub = 0; sub < s.nt; ++sub) {
+    const int64_t n0 = ns + (int64_t)sub * PS_TN;
+    if (n0 >= p.n) break;  // uniform: ragged last super-tile
+    read_a(0, Xs + sub * s.x_rows * PS_XS);
+    if (KS_MAX > 8 && s.passes > 1) {  // K > 256: second half of the rows through the same LDS image (nt == 1)
       __syncthreads();
       load_x(n0, 1);
       write_x();
       __syncthreads();
-      read_a(1);
+      read_a(1, Xs);
+      if (tile + 1 < tile_end) load_x(ns + super_px, 0);
     }
-    if (tile + 1 < tile_end) load_x(n0 + PS_TN, 0);  // next tile's rows fly while this one is multiplied
 
     const int64_t n = n0 + 16 * wv + 4 * g;  // this lane's 4 consecutive pixels
     for (int mb = 0; mb < mfrags; mb += PS_MF) {
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwS s) {
         }
       }
     }
+   }  // sub-tiles
   }
 }
 
@@ -227,9 +237,17 @@ int pw_stream_try(const PwK& k, int batch, hipStream_t st, int* launched) {
   s.mpad = wt ? (k.m + 31) / 32 * 32 : (k.m + 15) / 16 * 16;
   s.w_stride = wt ? s.mpad + 16 : s.kpad + 8;
   const size_t w_elems = ((size_t)(wt ? s.kpad : s.mpad) * s.w_stride + 7) & ~(size_t)7;
-  const size_t lds = (w_elems + (size_t)s.x_rows * PS_XS) * sizeof(bf16);
+  // (nt is chosen below; the X image never exceeds 256 rows in total)
+  const size_t lds = (w_elems + (size_t)256 * PS_XS) * sizeof(bf16);
   if (lds > 150 * 1024) return MI_OK;
-  s.n_tiles = cdiv(k.n, PS_TN);
+  s.nt = 1;
+  if (s.passes == 1) {  // as many sub-tiles as the 8 staging vectors per thread allow (kpad * nt <= 256)
+    s.nt = 256 / s.kpad;
+    if (s.nt > 4) s.nt = 4;
+    if (s.nt < 1) s.nt = 1;
+    while (s.nt > 1 && (int64_t)(s.nt - 1) * PS_TN >= k.n) --s.nt;
+  }
+  s.n_tiles = cdiv(k.n, PS_TN * s.nt);
   const int Z = batch * k.groups;
   const int64_t total_tiles = (int64_t)s.n_tiles * Z;
   // weights are re-staged per workgroup: only worth it when each workgroup gets a few tiles
@@ -237,7 +255,14 @@ int pw_stream_try(const PwK& k, int batch, hipStream_t st, int* launched) {
   int tpb = cdiv(total_tiles, target_blocks);
   if (tpb < 1) tpb = 1;
   if (tpb > s.n_tiles) tpb = s.n_tiles;
-  static const bool force = getenv("MI_PW_FORCE_STREAM") != nullptr;  // tests: exercise this kernel on small shapes
+  const bool force = getenv("MI_PW_FORCE_STREAM") != nullptr;  // tests: exercise this kernel on small shapes
+  // Measured on MI355X (profiles/r01_c_kernel_microbench.log): the chunked kernel is faster on every Restormer shape,
+  // so this form is opt-in (MI_PW_STREAM=1) until its per-tile phases overlap; kept because it is the base for the
+  // LDS-DMA ring version and is covered by exact-integer tests.
+  const bool on = getenv("MI_PW_STREAM") != nullptr;
+  const int tpb_env = getenv("MI_PW_TPB") ? atoi(getenv("MI_PW_TPB")) : 0;
+  if (!on && !force) return MI_OK;
+  if (tpb_env > 0) tpb = tpb_env < s.n_tiles ? tpb_env : s.n_tiles;
   if (!force && tpb < 2 && (size_t)k.m * ktot > 4096) return MI_OK;  // tiny images with large weights: chunked kernel
   s.tiles_per_block = tpb;
   dim3 grid(cdiv(s.n_tiles, tpb), Z), block(256);

@@ -42,24 +42,28 @@ ProfScope::~ProfScope() {
   if (kid >= 0 && kid < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[kid].e1, st);
 }
 
-// out[c] = (accumulate ? out[c] : 0) + scale * sum_r part[r*ld + c].  One thread per column chunk,
-// rows walked in a fixed order -> bitwise reproducible.  256 threads = 64 columns x 4 row-phases.
+// out[g][c] = (accumulate ? out[g][c] : 0) + scale * sum_{r in group g} part[r*ld + c].  Rows are walked in a fixed
+// order -> bitwise reproducible.  256 threads = 32 columns x 8 row-phases, 4 loads in flight per thread.
+// Row group g = blockIdx.y covers rows [g*rpg, min(rows, (g+1)*rpg)) and writes out + g*out_gs.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int64_t rows, int64_t cols, int64_t ld, int accumulate,
-                                                          float scale) {
+                                                          float scale, int64_t rpg, int64_t out_gs) {
   __shared__ float sm[8][32];
   const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + cx;
+  const int64_t r_begin = (int64_t)blockIdx.y * rpg;
+  int64_t r_end = r_begin + rpg;
+  if (r_end > rows) r_end = rows;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < cols) {
-    int64_t r = ph;
-    for (; r + 24 < rows; r += 32) {  // four loads in flight per thread; fixed order -> reproducible
+    int64_t r = r_begin + ph;
+    for (; r + 24 < r_end; r += 32) {
       a0 += part[r * ld + c];
       a1 += part[(r + 8) * ld + c];
       a2 += part[(r + 16) * ld + c];
       a3 += part[(r + 24) * ld + c];
     }
-    for (; r < rows; r += 8) a0 += part[r * ld + c];
+    for (; r < r_end; r += 8) a0 += part[r * ld + c];
   }
   sm[ph][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
@@ -67,16 +71,29 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += sm[k][cx];
-    out[c] = (accumulate ? out[c] : 0.f) + scale * t;
+    float* o = out + (int64_t)blockIdx.y * out_gs + c;
+    *o = (accumulate ? *o : 0.f) + scale * t;
   }
 }
 
+// tmp (optional, REDUCE_GROUPS*cols floats): when given and rows is large the sum runs in two stages so that the
+// long row walk is spread over REDUCE_GROUPS x (cols/32) workgroups instead of cols/32.
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate,
-                       float scale, hipStream_t st) {
+                       float scale, hipStream_t st, float* tmp) {
   if (cols <= 0) return MI_OK;
+  if (tmp && rows > 4 * REDUCE_GROUPS) {
+    const int64_t rpg = (rows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+    {
+      ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + REDUCE_GROUPS) * cols * 4, (double)rows * cols);
+      hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32), REDUCE_GROUPS), dim3(256), 0, st, part, tmp, rows, cols,
+                         part_ld, 0, 1.0f, rpg, cols);
+    }
+    MI_LAUNCH_CHECK();
+    part = tmp; rows = REDUCE_GROUPS; part_ld = cols;
+  }
   ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + 1) * cols * 4, (double)rows * cols);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, st, part, out, rows, cols, part_ld,
-                     accumulate, scale);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32), 1), dim3(256), 0, st, part, out, rows, cols, part_ld,
+                     accumulate, scale, rows, (int64_t)0);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-shape kernel microbenchmarks (run on the GPU box): python tools/bench_kernels.py [pw|ln|dw|gram]
+Times each call with HIP events on the current stream, prints algorithmic GB/s."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def bench_pw():
+    from image_restoration_amd import ops
+    B = 8
+    shapes = [  # (M, K, H, W, transposed, residual)
+        (144, 48, 256, 256, False, False), (48, 48, 256, 256, False, True), (254, 48, 256, 256, False, False),
+        (48, 127, 256, 256, False, True), (48, 144, 256, 256, True, False), (127, 48, 256, 256, True, False),
+        (48, 254, 256, 256, True, False),
+        (288, 96, 256, 256, False, False), (510, 96, 256, 256, False, False), (96, 255, 256, 256, False, True),
+        (96, 288, 256, 256, True, False), (96, 510, 256, 256, True, False),
+        (288, 96, 128, 128, False, False), (510, 96, 128, 128, False, False), (96, 255, 128, 128, False, True),
+        (576, 192, 64, 64, False, False), (1020, 192, 64, 64, False, False), (1152, 384, 32, 32, False, False),
+    ]
+    for (M, K, H, W, tr, res) in shapes:
+        x = torch.randn(B, K, H, W, device="cuda").bfloat16()
+        w = torch.randn((K, M) if tr else (M, K), device="cuda")
+        r = torch.randn(B, M, H, W, device="cuda").bfloat16() if res else None
+        us = timeit(lambda: ops.conv1x1(x, w, None, r, tr))
+        gb = (K + M + (M if res else 0)) * B * H * W * 2 / 1e9
+        print(f"pw M={M:4d} K={K:4d} {H}x{W} tr={int(tr)} res={int(res)}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s  "
+              f"{2 * M * K * B * H * W / us / 1e6:7.1f} TF/s", flush=True)
+
+
+def bench_ln():
+    from image_restoration_amd import ops
+    for (C, H, W) in [(48, 256, 256), (96, 256, 256), (96, 128, 128), (192, 64, 64), (384, 32, 32)]:
+        B = 8
+        x = torch.randn(B, C, H, W, device="cuda").bfloat16()
+        w, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        us = timeit(lambda: ops.ln_fwd(x, w, b, True))
+        y, mean, rstd = ops.ln_fwd(x, w, b, True)
+        print(f"ln_fwd C={C} {H}x{W}: {us:8.1f} us {2 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+        dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        us = timeit(lambda: ops.ln_bwd(x, x, w, mean, rstd, x, True, dw, db, False))
+        print(f"ln_bwd C={C} {H}x{W}: {us:8.1f} us {4 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+
+
+def bench_dw():
+    from image_restoration_amd import ops
+    for (C, H, W) in [(144, 256, 256), (254, 256, 256), (288, 256, 256), (510, 128, 128), (1020, 64, 64)]:
+        B = 8
+        x = torch.randn(B, C, H, W, device="cuda").bfloat16()
+        w = torch.randn(C, 1, 3, 3, device="cuda")
+        us = timeit(lambda: ops.dwconv_fwd(x, w, None))
+        print(f"dw_fwd  C={C} {H}x{W}: {us:8.1f} us {2 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+        us = timeit(lambda: ops.dwconv_bwd(x, x, w, False))
+        print(f"dw_bwd(data+wgrad) C={C} {H}x{W}: {us:8.1f} us {4 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+        if C % 2 == 0:
+            us = timeit(lambda: ops.dwconv_gate_fwd(x, w, None))
+            print(f"dw_gate_fwd C={C} {H}x{W}: {us:8.1f} us {2.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+
+
+def bench_gram():
+    from image_restoration_amd import ops
+    for (ma, mb, H, W, g, sb) in [(48, 48, 256, 256, 1, False), (96, 96, 256, 256, 1, False), (144, 48, 256, 256, 1, True),
+                                  (254, 48, 256, 256, 1, True), (510, 96, 256, 256, 1, True), (48, 127, 256, 256, 1, True),
+                                  (48, 48, 128, 128, 2, False), (1020, 192, 64, 64, 1, True)]:
+        B = 8
+        a = torch.randn(B, ma * g, H, W, device="cuda").bfloat16()
+        b = torch.randn(B, mb * g, H, W, device="cuda").bfloat16()
+        us = timeit(lambda: ops.gram(a, b, g, sb))
+        print(f"gram {ma}x{mb} g={g} {H}x{W} sum_batch={int(sb)}: {us:8.1f} us {(a.numel() + b.numel()) * 2 / us / 1e3:7.0f} GB/s",
+              flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pw", "ln", "dw", "gram"]
+    for wname in which:
+        {"pw": bench_pw, "ln": bench_ln, "dw": bench_dw, "gram": bench_gram}[wname]()
