@@ -79,7 +79,8 @@ SIGNATURES = {
                                 vp, vp]),
     "mi_dwconv_gate_bwd": (C.c_int, [vp, vp, vp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, vp, vp]),
-    "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp]),
+    "mi_pw_gemm_workspace": (C.c_size_t, [C.POINTER(PwDesc)]),
+    "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp, vp]),
     "mi_gram_workspace": (C.c_size_t, [C.POINTER(GramDesc)]),
     "mi_gram": (C.c_int, [C.POINTER(GramDesc), vp, vp]),
     "mi_mdta_saved_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),

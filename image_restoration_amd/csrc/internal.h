@@ -13,8 +13,6 @@ struct PwK {
   void* y; int64_t y_bs, y_gs;
   int m; int64_t n; int groups; int vec_ok;
 };
-int pw_stream_try(const PwK& k, int batch, hipStream_t st, int* launched);
-
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
                      float* nrm, float* M, int B, int C, int heads, hipStream_t st);
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,

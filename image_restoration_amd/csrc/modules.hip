@@ -10,6 +10,21 @@ static size_t fbytes(size_t n) { return align_up(n * sizeof(float), 256); }
 static size_t tbytes(size_t n, int dt) { return align_up(n * dtype_size(dt), 256); }
 template <typename A, typename B> static size_t max2(A a, B b) { return (size_t)a > (size_t)b ? (size_t)a : (size_t)b; }
 
+// plain 1x1 conv: y[B,M,N] = W[M,K] x[B,K,N] (+bias) (+res);  transposed: W given as [K,M] used as its transpose
+static mi_pw_desc conv1x1(const void* x, int K, const float* w, bool transposed, int w_ld, const float* bias,
+                          const void* res, void* y, int M, int B, int64_t N, int dtype) {
+  mi_pw_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x1 = x; d.x1_bs = (int64_t)K * N; d.k1 = K;
+  d.w = w;
+  if (transposed) { d.w_sm = 1; d.w_sk = w_ld; } else { d.w_sm = w_ld; d.w_sk = 1; }
+  d.bias = bias;
+  d.r = res; d.r_bs = (int64_t)M * N;
+  d.y = y; d.y_bs = (int64_t)M * N;
+  d.m = M; d.n = N; d.batch = B; d.groups = 1; d.dtype = dtype;
+  return d;
+}
+
 // ------------------------------------------------------------------ MDTA
 struct MdtaSaved {
   void* qkv0; void* qkv; float* A; float* P; float* nrm; float* M; size_t bytes;
@@ -65,7 +80,7 @@ static mi_gram_desc wgrad_gram(const void* dy, int m, const void* x, int k, int 
 
 struct MdtaWs {
   // forward
-  float* graw; float* ss; void* gram_ws; MdtaSaved inf;  // inf: saved-blob stand-in for inference
+  float* graw; float* ss; void* gram_ws; void* pw_ws; MdtaSaved inf;  // inf: saved-blob stand-in for inference
   // backward
   float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; void* dqkv; void* dqkv0; void* dw_ws;
   void* cs_ws;
@@ -88,6 +103,18 @@ static MdtaWs mdta_ws_layout(const mi_mdta_shape* s, void* base) {
   mi_gram_desc g3 = wgrad_gram((void*)256, 3 * (int)C, (void*)256, (int)C, (int)B, (int64_t)N, s->dtype, (float*)256, 0);
   size_t gw = max2(mi_gram_workspace(&g1), max2(mi_gram_workspace(&g2), mi_gram_workspace(&g3)));
   w.gram_ws = cv.take(gw);
+  {  // weight-pack scratch of the largest 1x1 GEMM of this module (qkv: 3C x C; per-image c x 2c and C x C slices)
+    mi_pw_desc a = conv1x1((void*)256, (int)C, (const float*)256, false, (int)C, nullptr, nullptr, (void*)256, 3 * (int)C,
+                           (int)B, (int64_t)N, s->dtype);
+    mi_pw_desc b = a;
+    b.m = (int)C; b.w_bs = (int64_t)C * C;  // per-image C x C (M_b and its transpose)
+    mi_pw_desc d = a;
+    d.m = (int)c; d.k1 = (int)c; d.k2 = (int)c; d.x2 = (void*)256; d.groups = s->heads; d.w_bs = 1; d.w_gs = 1;
+    mi_pw_desc e = conv1x1((void*)256, 3 * (int)C, (const float*)256, true, (int)C, nullptr, nullptr, (void*)256, (int)C,
+                           (int)B, (int64_t)N, s->dtype);  // input gradient: W_qkv^T
+    w.pw_ws = cv.take(max2(max2(mi_pw_gemm_workspace(&a), mi_pw_gemm_workspace(&e)),
+                           max2(mi_pw_gemm_workspace(&b), mi_pw_gemm_workspace(&d))));
+  }
   w.dw_ws = cv.take(mi_dwconv_bwd_workspace((int)B, 3 * (int)C, s->H, s->W, s->ks));
   w.cs_ws = cv.take(chan_sum_workspace(3 * (int)C, (int64_t)N));
   // big activation-sized buffers last: forward(inference) and backward never run concurrently on one blob
@@ -121,7 +148,7 @@ static GdfnSaved gdfn_saved_layout(const mi_gdfn_shape* s, void* base) {
   r.bytes = cv.off;
   return r;
 }
-struct GdfnWs { void* gram_ws; void* dw_ws; void* cs_ws; GdfnSaved inf; void* dg; void* dh0; size_t bytes; };
+struct GdfnWs { void* gram_ws; void* pw_ws; void* dw_ws; void* cs_ws; GdfnSaved inf; void* dg; void* dh0; size_t bytes; };
 static GdfnWs gdfn_ws_layout(const mi_gdfn_shape* s, void* base) {
   const size_t N = (size_t)s->H * s->W, B = s->B, h = s->hidden, C = s->C;
   Carver cv(base);
@@ -129,6 +156,13 @@ static GdfnWs gdfn_ws_layout(const mi_gdfn_shape* s, void* base) {
   mi_gram_desc g1 = wgrad_gram((void*)256, (int)C, (void*)256, (int)h, (int)B, (int64_t)N, s->dtype, (float*)256, 0);
   mi_gram_desc g2 = wgrad_gram((void*)256, 2 * (int)h, (void*)256, (int)C, (int)B, (int64_t)N, s->dtype, (float*)256, 0);
   w.gram_ws = cv.take(max2(mi_gram_workspace(&g1), mi_gram_workspace(&g2)));
+  {
+    mi_pw_desc a = conv1x1((void*)256, (int)C, (const float*)256, false, (int)C, nullptr, nullptr, (void*)256, 2 * (int)h,
+                           (int)B, (int64_t)N, s->dtype);
+    mi_pw_desc b = conv1x1((void*)256, 2 * (int)h, (const float*)256, true, (int)C, nullptr, nullptr, (void*)256, (int)C,
+                           (int)B, (int64_t)N, s->dtype);
+    w.pw_ws = cv.take(max2(mi_pw_gemm_workspace(&a), mi_pw_gemm_workspace(&b)));
+  }
   w.dw_ws = cv.take(mi_dwconv_bwd_workspace((int)B, 2 * (int)h, s->H, s->W, s->ks));
   w.cs_ws = cv.take(chan_sum_workspace(2 * (int)h > (int)C ? 2 * (int)h : (int)C, (int64_t)N));
   size_t mark = cv.off;
@@ -145,21 +179,6 @@ static int gdfn_check(const mi_gdfn_shape* s) {
   MI_CHECK_ARG(s->dtype == MI_F32 || s->dtype == MI_BF16, "gdfn: bad dtype %d", s->dtype);
   MI_CHECK_ARG(s->ks == 3 || s->ks == 5 || s->ks == 7, "gdfn: bad depthwise kernel size %d", s->ks);
   return MI_OK;
-}
-
-// plain 1x1 conv: y[B,M,N] = W[M,K] x[B,K,N] (+bias) (+res);  transposed: W given as [K,M] used as its transpose
-static mi_pw_desc conv1x1(const void* x, int K, const float* w, bool transposed, int w_ld, const float* bias,
-                          const void* res, void* y, int M, int B, int64_t N, int dtype) {
-  mi_pw_desc d;
-  memset(&d, 0, sizeof(d));
-  d.x1 = x; d.x1_bs = (int64_t)K * N; d.k1 = K;
-  d.w = w;
-  if (transposed) { d.w_sm = 1; d.w_sk = w_ld; } else { d.w_sm = w_ld; d.w_sk = 1; }
-  d.bias = bias;
-  d.r = res; d.r_bs = (int64_t)M * N;
-  d.y = y; d.y_bs = (int64_t)M * N;
-  d.m = M; d.n = N; d.batch = B; d.groups = 1; d.dtype = dtype;
-  return d;
 }
 
 }  // namespace mi
@@ -189,7 +208,7 @@ extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
 
   // qkv0 = qkv(x);  qkv = dw(qkv0)                               Restormer.py:114
   mi_pw_desc d1 = conv1x1(x, C, p->qkv_w, false, C, p->qkv_b, nullptr, sv.qkv0, 3 * C, B, N, dt);
-  MI_TRY(mi_pw_gemm(&d1, stream));
+  MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
   MI_TRY(mi_dwconv_fwd(sv.qkv0, p->dw_w, p->dw_b, sv.qkv, B, 3 * C, s->H, s->W, s->ks, dt, stream));
   // q k^T per head + row sums of squares                          Restormer.py:121-124
   mi_gram_desc g = mdta_qk_gram(s, sv.qkv, w.graw, w.ss);
@@ -200,7 +219,7 @@ extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   mi_pw_desc d2 = conv1x1((const char*)sv.qkv + (size_t)2 * C * N * es, C, sv.M, false, C, p->proj_b, residual, out, C, B, N, dt);
   d2.x1_bs = 3 * (int64_t)C * N;
   d2.w_bs = (int64_t)C * C;
-  MI_TRY(mi_pw_gemm(&d2, stream));
+  MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
 }
 
@@ -237,14 +256,14 @@ extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   dd.w = w.wdq; dd.w_bs = (int64_t)hd * c * 2 * c; dd.w_gs = (int64_t)c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
   dd.y = dq; dd.y_bs = 3 * (int64_t)C * N; dd.y_gs = (int64_t)c * N;
   dd.m = c; dd.n = N; dd.batch = B; dd.groups = hd; dd.dtype = dt;
-  MI_TRY(mi_pw_gemm(&dd, stream));
+  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
   dd.x1 = q; dd.x2 = k; dd.w = w.wdk; dd.y = dk;
-  MI_TRY(mi_pw_gemm(&dd, stream));
+  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
   // dv = M_b^T dY
   mi_pw_desc dvd = conv1x1(dout, C, sv.M, true, C, nullptr, nullptr, dv, C, B, N, dt);
   dvd.w_bs = (int64_t)C * C;
   dvd.y_bs = 3 * (int64_t)C * N;
-  MI_TRY(mi_pw_gemm(&dvd, stream));
+  MI_TRY(mi_pw_gemm(&dvd, w.pw_ws, stream));
   // depthwise backward: d_qkv -> d_qkv0, weight/bias grads
   MI_TRY(mi_dwconv_bwd(w.dqkv, sv.qkv0, p->dw_w, w.dqkv0, gr->dw_w, gr->dw_b, B, 3 * C, s->H, s->W, s->ks, acc, dt, w.dw_ws,
                        stream));
@@ -253,7 +272,7 @@ extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   MI_TRY(mi_gram(&g2, w.gram_ws, stream));
   if (gr->qkv_b) MI_TRY(launch_chan_sum(w.dqkv0, gr->qkv_b, B, 3 * C, N, dt, acc, w.cs_ws, st));
   mi_pw_desc dxd = conv1x1(w.dqkv0, 3 * C, p->qkv_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
-  MI_TRY(mi_pw_gemm(&dxd, stream));
+  MI_TRY(mi_pw_gemm(&dxd, w.pw_ws, stream));
   return MI_OK;
 }
 
@@ -276,11 +295,11 @@ extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   GdfnWs w = gdfn_ws_layout(s, ws);
   GdfnSaved sv = saved ? gdfn_saved_layout(s, saved) : w.inf;
   mi_pw_desc d1 = conv1x1(x, C, p->in_w, false, C, p->in_b, nullptr, sv.h0, 2 * h, B, N, dt);       // Restormer.py:89
-  MI_TRY(mi_pw_gemm(&d1, stream));
+  MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
   MI_TRY(mi_dwconv_gate_fwd(sv.h0, p->dw_w, p->dw_b, saved ? sv.h1 : nullptr, sv.g, B, 2 * h, s->H, s->W, s->ks, dt,
                             stream));                                                                // :90-91
   mi_pw_desc d2 = conv1x1(sv.g, h, p->out_w, false, h, p->out_b, residual, out, C, B, N, dt);       // :92
-  MI_TRY(mi_pw_gemm(&d2, stream));
+  MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
 }
 
@@ -298,13 +317,13 @@ extern "C" int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   mi_gram_desc g1 = wgrad_gram(dout, C, sv.g, h, B, N, dt, gr->out_w, acc);
   MI_TRY(mi_gram(&g1, w.gram_ws, stream));
   mi_pw_desc d1 = conv1x1(dout, C, p->out_w, true, h, nullptr, nullptr, w.dg, h, B, N, dt);
-  MI_TRY(mi_pw_gemm(&d1, stream));
+  MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
   MI_TRY(mi_dwconv_gate_bwd(w.dg, sv.h1, sv.h0, p->dw_w, w.dh0, gr->dw_w, gr->dw_b, B, 2 * h, s->H, s->W, s->ks, acc, dt,
                             w.dw_ws, stream));
   mi_gram_desc g2 = wgrad_gram(w.dh0, 2 * h, x, C, B, N, dt, gr->in_w, acc);
   MI_TRY(mi_gram(&g2, w.gram_ws, stream));
   if (gr->in_b) MI_TRY(launch_chan_sum(w.dh0, gr->in_b, B, 2 * h, N, dt, acc, w.cs_ws, st));
   mi_pw_desc d2 = conv1x1(w.dh0, 2 * h, p->in_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
-  MI_TRY(mi_pw_gemm(&d2, stream));
+  MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
 }

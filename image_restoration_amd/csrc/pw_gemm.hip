@@ -1,10 +1,12 @@
 // Pointwise (1x1-conv) GEMM on N-contiguous NCHW planes, MFMA tiles for gfx950.
 //   Y[z][m][n] = sum_k W_z(m,k) X[z][k][n] (+bias[m]) (+R[z][m][n])
 // Orientation: the MFMA "A" operand is X^T (rows = pixels), "B" is W^T (cols = output channels), so the
-// accumulator holds 4 consecutive pixels of one output channel per lane -> packed 8/16-byte stores
-// along the contiguous pixel axis.  X is staged [k][n] exactly as it lies in HBM (coalesced 16-byte
-// loads) and transposed for free on the LDS read (ds_read_b64_tr_b16); weights are staged either
-// row-major [m][k] or, for transposed-weight calls (backward-data), [k][m] and read the same way.
+// accumulator holds 4 consecutive pixels of one output channel per lane.  X is staged [k][n] exactly as it lies in
+// HBM (coalesced 16-byte loads) and transposed for free on the LDS read (ds_read_b64_tr_b16).  Weights are first
+// re-packed by a tiny kernel into the exact LDS image the main kernel wants ([m-tile][k-chunk][TM][row stride],
+// activation dtype, zero padded, transposed if the caller passed W^T), so staging a weight chunk is a straight
+// 16-byte copy (measured: per-tile scalar fp32 staging cost more issue slots than everything else in the kernel).
+// The epilogue stages accumulators through LDS and writes whole 128-byte row segments, 16 bytes per lane.
 // bf16 activations use v_mfma_f32_16x16x32_bf16, fp32 activations the exact v_mfma_f32_16x16x4_f32.
 #include <type_traits>
 
@@ -16,13 +18,7 @@ constexpr int PW_TN = 64;  // pixels per workgroup tile
 constexpr int PW_KC = 32;  // k per staged chunk
 constexpr int PW_XS = 80;  // LDS row stride (elements) of the X chunk: conflict-free tr-reads / b32 reads
 
-
-template <typename T, int TM, bool WT> struct PwLds {
-  static constexpr int WS_ROW = std::is_same<T, float>::value ? 34 : 40;  // [m][k] row stride
-  static constexpr int WS_T = TM + 16;                                   // [k][m] row stride
-  static constexpr int W_ELEMS = WT ? PW_KC * WS_T : TM * WS_ROW;
-  static constexpr int X_ELEMS = PW_KC * PW_XS;
-};
+template <typename T> struct PwRow { static constexpr int WS_ROW = std::is_same<T, float>::value ? 34 : 40; };
 
 __device__ __forceinline__ s16x4 lds_tr_b16(const void* p) {
   s16x4 v;
@@ -31,16 +27,50 @@ __device__ __forceinline__ s16x4 lds_tr_b16(const void* p) {
   return v;
 }
 
-template <typename T, int MF, bool WT>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
+// ---- weight re-pack: fp32 W(m,k) (any strides) -> T image [slice][m_tile][k_chunk][TM][WS_ROW] ----
+template <typename T>
+__global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, int64_t w_bs, int64_t w_gs, int64_t w_sm,
+                                                      int64_t w_sk, T* __restrict__ out, int M, int K, int tm, int k_chunks,
+                                                      int groups_w, int64_t slice_elems, int m_fast) {
+  constexpr int WS_ROW = PwRow<T>::WS_ROW;
+  const int slice = blockIdx.y;
+  const int sb = slice / groups_w, sg = slice - sb * groups_w;
+  const float* wz = w + sb * w_bs + sg * w_gs;
+  T* oz = out + (int64_t)slice * slice_elems;
+  const int m_tiles = (int)(slice_elems / ((int64_t)k_chunks * tm * WS_ROW));
+  const int64_t total = (int64_t)m_tiles * k_chunks * tm * PW_KC;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    // m_fast: consecutive threads walk m (coalesced for W^T callers), else k
+    int64_t r = e;
+    int kk, mm;
+    if (m_fast) { mm = (int)(r % tm); r /= tm; kk = (int)(r % PW_KC); r /= PW_KC; }
+    else { kk = (int)(r % PW_KC); r /= PW_KC; mm = (int)(r % tm); r /= tm; }
+    const int kc = (int)(r % k_chunks), mt = (int)(r / k_chunks);
+    const int m = mt * tm + mm, k = kc * PW_KC + kk;
+    const float v = (m < M && k < K) ? wz[(int64_t)m * w_sm + (int64_t)k * w_sk] : 0.f;
+    oz[(((int64_t)mt * k_chunks + kc) * tm + mm) * WS_ROW + kk] = Cvt<T>::from(v);
+  }
+}
+
+struct PwG {
+  PwK k;
+  const void* wp;        // packed weights
+  int64_t wp_slice;      // elements per packed slice
+  int wp_per_batch, wp_per_group, k_chunks;
+};
+
+template <typename T, int MF>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
+  const PwK& p = q.k;
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int TM = 64 * MF;
-  using L = PwLds<T, TM, WT>;
-  constexpr int STAGE_BYTES = (L::X_ELEMS + L::W_ELEMS) * (int)sizeof(T);
+  constexpr int WS_ROW = PwRow<T>::WS_ROW;
+  constexpr int X_ELEMS = PW_KC * PW_XS, W_ELEMS = TM * WS_ROW;
+  constexpr int STAGE_BYTES = (X_ELEMS + W_ELEMS) * (int)sizeof(T);
   constexpr int SLAB_BYTES = 4 * 16 * (PW_TN + 4) * (int)sizeof(float);  // epilogue: 4 waves x 16 rows x fp32
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES];
   T* const Xs = reinterpret_cast<T*>(lds_raw);
-  T* const Ws = Xs + L::X_ELEMS;
+  T* const Ws = Xs + X_ELEMS;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -48,17 +78,19 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
   const int64_t n0 = (int64_t)blockIdx.x * PW_TN;
   const int m0 = blockIdx.y * TM;
   const int ktot = p.k1 + p.k2;
-  const int nchunks = (ktot + PW_KC - 1) / PW_KC;
+  const int nchunks = q.k_chunks;
 
   const T* x1 = (const T*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
   const T* x2 = p.x2 ? (const T*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : nullptr;
-  const float* wz = p.w + zb * p.w_bs + zg * p.w_gs;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  const u32x4* wpk = reinterpret_cast<const u32x4*>((const T*)q.wp + (int64_t)wslice * q.wp_slice +
+                                                    (int64_t)blockIdx.y * nchunks * W_ELEMS);
 
   // ---- staging registers ----
-  constexpr int XV = F32 ? 2 : 1;      // 16-byte vectors per thread for its 8 X elements
-  constexpr int WP = TM / 16;          // weight pairs per thread per chunk
-  u32x4 xreg[XV];
-  float wreg[WP][2];
+  constexpr int XV = F32 ? 2 : 1;                             // 16-byte vectors per thread for its 8 X elements
+  constexpr int W_VECS = W_ELEMS * (int)sizeof(T) / 16;       // 16-byte vectors per weight chunk image
+  constexpr int WV = (W_VECS + 255) / 256;
+  u32x4 xreg[XV], wreg[WV];
   const int xr_row = t >> 3, xr_col = (t & 7) * 8;
 
   auto load_stage = [&](int chunk) {
@@ -67,47 +99,35 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
     if (k < p.k1) row = x1 + (int64_t)k * p.n;
     else if (k < ktot) row = x2 + (int64_t)(k - p.k1) * p.n;
     const int64_t n = n0 + xr_col;
-    constexpr int EPV = 8 / XV;  // elements per 16-byte vector
+    constexpr int EPVX = 8 / XV;  // elements per 16-byte vector
 #pragma unroll
     for (int v = 0; v < XV; ++v) {
-      const int64_t nn = n + v * EPV;
-      if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPV == 0 for every row, so the vector is all-in or all-out
+      const int64_t nn = n + v * EPVX;
+      if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPVX == 0 for every row, so the vector is all-in or all-out
         xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
       } else {
-        __attribute__((aligned(16))) T tmp[EPV];
+        __attribute__((aligned(16))) T tmp[EPVX];
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) tmp[j] = (row && nn + j < p.n) ? row[nn + j] : Cvt<T>::from(0.f);
+        for (int j = 0; j < EPVX; ++j) tmp[j] = (row && nn + j < p.n) ? row[nn + j] : Cvt<T>::from(0.f);
         xreg[v] = *reinterpret_cast<u32x4*>(tmp);
       }
     }
+    const u32x4* wc = wpk + (int64_t)chunk * W_VECS;
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      const int idx = t + 256 * i;
-      int m, k2;
-      if (WT) { k2 = idx / (TM / 2); m = (idx - k2 * (TM / 2)) * 2; }
-      else { m = idx >> 4; k2 = (idx & 15) * 2; }
-      const int kk = chunk * PW_KC + k2;
-      const int mm = m0 + m;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int me = WT ? mm + e : mm, ke = WT ? kk : kk + e;
-        wreg[i][e] = (me < p.m && ke < ktot) ? wz[(int64_t)me * p.w_sm + (int64_t)ke * p.w_sk] : 0.f;
-      }
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wreg[i] = wc[vid];
     }
   };
   auto write_stage = [&]() {
 #pragma unroll
     for (int v = 0; v < XV; ++v)
       *reinterpret_cast<u32x4*>(&Xs[xr_row * PW_XS + xr_col + v * (8 / XV)]) = xreg[v];
+    u32x4* wd = reinterpret_cast<u32x4*>(Ws);
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      const int idx = t + 256 * i;
-      int m, k2;
-      if (WT) { k2 = idx / (TM / 2); m = (idx - k2 * (TM / 2)) * 2; }
-      else { m = idx >> 4; k2 = (idx & 15) * 2; }
-      T* dst = WT ? &Ws[k2 * L::WS_T + m] : &Ws[m * L::WS_ROW + k2];
-      float pr[2] = {wreg[i][0], wreg[i][1]};
-      Vec<T, 2>::st(dst, pr);
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wd[vid] = wreg[i];
     }
   };
 
@@ -133,8 +153,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) a[nf] = Xs[kk * PW_XS + 16 * nf + li];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-          b[mf] = WT ? Ws[kk * L::WS_T + mw + 16 * mf + li] : Ws[(mw + 16 * mf + li) * L::WS_ROW + kk];
+        for (int mf = 0; mf < MF; ++mf) b[mf] = Ws[(mw + 16 * mf + li) * WS_ROW + kk];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
@@ -145,33 +164,24 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
       // k slots: element j<4 of lane group g is k = 4g+j, element j>=4 is k = 16+4g+(j-4), for A and B alike.
       // The tr-reads are inline asm, so their results are tied through the s_waitcnt statement below:
       // every consumer is data-dependent on the wait and cannot be scheduled ahead of it.
-      const int q = li >> 2, pp = li & 3;
+      const int qq = li >> 2, pp = li & 3;
       s16x4 alo[4], ahi[4], blo[MF], bhi[MF];
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) {
-        alo[nf] = lds_tr_b16(&Xs[(4 * g + q) * PW_XS + 16 * nf + 4 * pp]);
-        ahi[nf] = lds_tr_b16(&Xs[(16 + 4 * g + q) * PW_XS + 16 * nf + 4 * pp]);
+        alo[nf] = lds_tr_b16(&Xs[(4 * g + qq) * PW_XS + 16 * nf + 4 * pp]);
+        ahi[nf] = lds_tr_b16(&Xs[(16 + 4 * g + qq) * PW_XS + 16 * nf + 4 * pp]);
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        if (WT) {
-          blo[mf] = lds_tr_b16(&Ws[(4 * g + q) * L::WS_T + mw + 16 * mf + 4 * pp]);
-          bhi[mf] = lds_tr_b16(&Ws[(16 + 4 * g + q) * L::WS_T + mw + 16 * mf + 4 * pp]);
-        } else {
-          const T* wr = &Ws[(mw + 16 * mf + li) * L::WS_ROW + 4 * g];
-          blo[mf] = *reinterpret_cast<const s16x4*>(wr);
-          bhi[mf] = *reinterpret_cast<const s16x4*>(wr + 16);
-        }
+        const T* wr = &Ws[(mw + 16 * mf + li) * WS_ROW + 4 * g];
+        blo[mf] = *reinterpret_cast<const s16x4*>(wr);
+        bhi[mf] = *reinterpret_cast<const s16x4*>(wr + 16);
       }
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
                      "+v"(ahi[3])
                    :
                    : "memory");
-      if (WT) {
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) asm volatile("" : "+v"(blo[mf]), "+v"(bhi[mf]));
-      }
       s16x8 a[4], b[MF];
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) a[nf] = __builtin_shufflevector(alo[nf], ahi[nf], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -237,22 +247,58 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwK p) {
   }
 }
 
-template <typename T, bool WT>
-static int pw_launch(const PwK& k, int batch, hipStream_t st) {
+struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group; int64_t slice_elems; size_t bytes; };
+
+static PwPlan pw_plan(const mi_pw_desc* d) {
+  PwPlan pl;
   // largest m-tile whose padding stays within 25% of the 64-granular minimum
-  const int mmin = cdiv(k.m, 64) * 64;
-  int tm = 64;
-  if (cdiv(k.m, 256) * 256 * 4 <= mmin * 5) tm = 256;
-  else if (cdiv(k.m, 128) * 128 * 4 <= mmin * 5) tm = 128;
-  dim3 grid(cdiv(k.n, PW_TN), cdiv(k.m, tm), batch * k.groups), block(256);
+  const int mmin = cdiv(d->m, 64) * 64;
+  pl.tm = 64;
+  if (cdiv(d->m, 256) * 256 * 4 <= mmin * 5) pl.tm = 256;
+  else if (cdiv(d->m, 128) * 128 * 4 <= mmin * 5) pl.tm = 128;
+  pl.m_tiles = cdiv(d->m, pl.tm);
+  pl.k_chunks = cdiv(d->k1 + d->k2, PW_KC);
+  pl.per_batch = d->w_bs != 0;
+  pl.per_group = d->w_gs != 0;
+  pl.slices = (pl.per_batch ? d->batch : 1) * (pl.per_group ? d->groups : 1);
+  const int ws_row = d->dtype == MI_F32 ? PwRow<float>::WS_ROW : PwRow<bf16>::WS_ROW;
+  pl.slice_elems = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * ws_row;
+  pl.bytes = align_up((size_t)pl.slices * pl.slice_elems * dtype_size(d->dtype), 256);
+  return pl;
+}
+
+template <typename T>
+static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* ws, hipStream_t st) {
+  {  // re-pack the weights of every slice
+    const int64_t total = pl.slice_elems / PwRow<T>::WS_ROW * PW_KC;
+    int gx = cdiv(total, 256);
+    if (gx > 1024) gx = 1024;
+    ProfScope ps(st, K_PW_PACK, 4.0 * d->m * (d->k1 + d->k2) * pl.slices + (double)pl.bytes, 0.0);
+    hipLaunchKernelGGL((pw_pack_kernel<T>), dim3(gx, pl.slices), dim3(256), 0, st, d->w, d->w_bs, d->w_gs, d->w_sm, d->w_sk,
+                       (T*)ws, d->m, d->k1 + d->k2, pl.tm, pl.k_chunks, pl.per_group ? d->groups : 1, pl.slice_elems,
+                       d->w_sk != 1 ? 1 : 0);
+    MI_LAUNCH_CHECK();
+  }
+  PwG q;
+  q.k = k; q.wp = ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch; q.wp_per_group = pl.per_group;
+  q.k_chunks = pl.k_chunks;
+  dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
-  const double Z = (double)batch * k.groups, kt = k.k1 + k.k2;
+  const double Z = (double)d->batch * k.groups, kt = k.k1 + k.k2;
   ProfScope ps(st, K_PW_GEMM, (kt + k.m + (k.r ? k.m : 0)) * (double)k.n * Z * sizeof(T) + 4.0 * k.m * kt,
                2.0 * k.m * kt * (double)k.n * Z);
-  if (tm == 256) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, WT>), grid, block, 0, st, k);
-  else if (tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, WT>), grid, block, 0, st, k);
-  else hipLaunchKernelGGL((pw_gemm_kernel<T, 1, WT>), grid, block, 0, st, k);
+  if (pl.tm == 256) hipLaunchKernelGGL((pw_gemm_kernel<T, 4>), grid, block, 0, st, q);
+  else if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, q);
+  else hipLaunchKernelGGL((pw_gemm_kernel<T, 1>), grid, block, 0, st, q);
   MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+static int pw_check(const mi_pw_desc* d) {
+  MI_CHECK_ARG(d && d->x1 && d->w && d->y, "pw_gemm: null pointer");
+  MI_CHECK_ARG(d->m > 0 && d->n > 0 && d->k1 > 0 && d->k2 >= 0 && d->batch > 0 && d->groups > 0, "pw_gemm: bad shape");
+  MI_CHECK_ARG((d->k2 == 0) == (d->x2 == nullptr), "pw_gemm: x2/k2 mismatch");
+  MI_CHECK_ARG(d->dtype == MI_F32 || d->dtype == MI_BF16, "pw_gemm: bad dtype %d", d->dtype);
   return MI_OK;
 }
 
@@ -260,12 +306,14 @@ static int pw_launch(const PwK& k, int batch, hipStream_t st) {
 
 using namespace mi;
 
-extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* stream) {
-  MI_CHECK_ARG(d && d->x1 && d->w && d->y, "pw_gemm: null pointer");
-  MI_CHECK_ARG(d->m > 0 && d->n > 0 && d->k1 > 0 && d->k2 >= 0 && d->batch > 0 && d->groups > 0, "pw_gemm: bad shape");
-  MI_CHECK_ARG((d->k2 == 0) == (d->x2 == nullptr), "pw_gemm: x2/k2 mismatch");
-  MI_CHECK_ARG(d->dtype == MI_F32 || d->dtype == MI_BF16, "pw_gemm: bad dtype %d", d->dtype);
-  MI_CHECK_ARG(d->w_sm == 1 || d->w_sk == 1, "pw_gemm: weight must be contiguous along m or k");
+extern "C" size_t mi_pw_gemm_workspace(const mi_pw_desc* d) {
+  if (!d || d->m <= 0 || d->k1 <= 0 || d->k2 < 0 || d->batch <= 0 || d->groups <= 0) return 0;
+  return pw_plan(d).bytes;
+}
+
+extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
+  MI_TRY(pw_check(d));
+  MI_CHECK_ARG(ws && aligned16(ws), "pw_gemm: workspace missing or not 16-byte aligned");
   const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
   PwK k;
   k.x1 = d->x1; k.x1_bs = d->x1_bs; k.x1_gs = d->x1_gs; k.k1 = d->k1;
@@ -279,13 +327,8 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* stream) {
   ok = ok && d->x1_bs % vec == 0 && d->x1_gs % vec == 0 && d->x2_bs % vec == 0 && d->x2_gs % vec == 0;
   ok = ok && d->y_bs % vec == 0 && d->y_gs % vec == 0 && d->r_bs % vec == 0 && d->r_gs % vec == 0;
   k.vec_ok = ok ? 1 : 0;
-  const bool wt = (d->w_sk != 1);  // m-contiguous weights: stage [k][m]
+  const PwPlan pl = pw_plan(d);
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == MI_BF16) {  // HBM-bound shapes: weights resident in LDS, tiles streamed (pw_stream.hip)
-    int launched = 0;
-    MI_TRY(pw_stream_try(k, d->batch, st, &launched));
-    if (launched) return MI_OK;
-  }
-  if (d->dtype == MI_F32) return wt ? pw_launch<float, true>(k, d->batch, st) : pw_launch<float, false>(k, d->batch, st);
-  return wt ? pw_launch<bf16, true>(k, d->batch, st) : pw_launch<bf16, false>(k, d->batch, st);
+  if (d->dtype == MI_F32) return pw_launch<float>(d, k, pl, ws, st);
+  return pw_launch<bf16>(d, k, pl, ws, st);
 }

@@ -149,8 +149,14 @@ def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     d.r, d.r_bs, d.r_gs = _p(residual), M * N, 0
     d.y, d.y_bs, d.y_gs = _p(y), M * N, 0
     d.m, d.n, d.batch, d.groups, d.dtype = M, N, B, 1, _dt(x)
-    L.check(L.lib().mi_pw_gemm(C.byref(d), _stream()), "pw_gemm")
+    pw_gemm_desc(d, x.device)
     return y
+
+
+def pw_gemm_desc(d: "L.PwDesc", device) -> None:
+    """Run one mi_pw_gemm call described by ``d`` (allocates its weight-pack workspace)."""
+    ws = _blob(L.lib().mi_pw_gemm_workspace(C.byref(d)), device)
+    L.check(L.lib().mi_pw_gemm(C.byref(d), _p(ws), _stream()), "pw_gemm")
 
 
 def gram(a: Tensor, b: Tensor, groups: int = 1, sum_batch: bool = False, want_sumsq: bool = False):

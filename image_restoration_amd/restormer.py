@@ -204,7 +204,7 @@ def _dgrad_panel(dy: Tensor, w2: Tensor, k0: int, k: int) -> Tensor:
     d.w_sm, d.w_sk = 1, w2.shape[1]
     d.y, d.y_bs = dx.data_ptr(), k * N
     d.m, d.n, d.batch, d.groups, d.dtype = k, N, B, 1, ops._dt(dy)
-    L.check(L.lib().mi_pw_gemm(C.byref(d), ops._stream()), "pw_gemm(dgrad panel)")
+    ops.pw_gemm_desc(d, dy.device)
     return dx
 
 

@@ -89,7 +89,8 @@ int mi_dwconv_gate_bwd(const void* dg, const void* y, const void* x, const float
  * X2 rows K1..K1+K2-1): concat-free 1x1 over a channel concat.
  * Weight element (m,k) of slice z lives at W[b*w_bs + g*w_gs + m*w_sm + k*w_sk]
  * (w_sk==1: row-major [M,K]; w_sm==1: the transpose of a [K,M] matrix).
- * Strides are in elements.
+ * Strides are in elements.  ws: mi_pw_gemm_workspace() bytes (16-byte aligned); it receives the
+ * weights re-packed into the kernel's LDS image (activation dtype), written and read by this call only.
  * ------------------------------------------------------------------------ */
 typedef struct {
   const void* x1; int64_t x1_bs, x1_gs; int k1;
@@ -100,7 +101,8 @@ typedef struct {
   void* y; int64_t y_bs, y_gs;
   int m; int64_t n; int batch; int groups; int dtype;
 } mi_pw_desc;
-int mi_pw_gemm(const mi_pw_desc* d, void* stream);
+size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
+int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
  * Row-Gram (reduction over the pixel axis), the contraction of MDTA's q k^T

@@ -213,7 +213,7 @@ def test_l1_loss(dtype):
     assert rel(da, torch.sign(a.double() - b.double()) / a.numel()) < 1e-2
 
 
-# --------------------------------------------------------------------------- streaming pointwise GEMM (bf16)
+# --------------------------------------------------------------------------- pointwise GEMM, full descriptor
 def _pw_raw(x1, x2, w, bias, res, M, groups, w_per_image, transposed):
     """Full mi_pw_desc call: x [B, groups*K, H, W] split head-major into groups; w [(B,) groups, M, K] or its transpose."""
     import ctypes as C
@@ -238,7 +238,7 @@ def _pw_raw(x1, x2, w, bias, res, M, groups, w_per_image, transposed):
         d.r, d.r_bs, d.r_gs = res.data_ptr(), groups * M * N, M * N
     d.y, d.y_bs, d.y_gs = y.data_ptr(), groups * M * N, M * N
     d.m, d.n, d.batch, d.groups, d.dtype = M, N, B, groups, o._dt(x1)
-    L.check(L.lib().mi_pw_gemm(C.byref(d), o._stream()), "pw_gemm")
+    o.pw_gemm_desc(d, x1.device)
     return y
 
 
@@ -249,24 +249,23 @@ def _pw_raw(x1, x2, w, bias, res, M, groups, w_per_image, transposed):
     (288, 96, 0, 1, False, (8, 64)), (96, 255, 0, 1, False, (8, 64)), (96, 288, 0, 1, False, (8, 64)),
     (96, 510, 0, 1, False, (8, 64)), (510, 96, 0, 1, False, (8, 64)), (48, 48, 48, 2, True, (16, 64)),
     (96, 96, 96, 1, True, (8, 72)), (37, 20, 13, 3, True, (5, 7)), (48, 48, 0, 1, True, (9, 11))])
-def test_pw_stream_exact_on_integers(monkeypatch, transposed, M, K1, K2, groups, per_image, hw):
-    """The LDS-resident-weight streaming kernel (bf16): forced on, every k-step count (K 48..510, two X passes),
-    both weight orientations, two K-panels, head groups, per-image weights, ragged pixel counts.  Integer data: exact
-    up to the final bf16 rounding of the store."""
-    monkeypatch.setenv("MI_PW_FORCE_STREAM", "1")
+@pytest.mark.parametrize("dtype", DT)
+def test_pw_full_descriptor_exact_on_integers(dtype, transposed, M, K1, K2, groups, per_image, hw):
+    """The full mi_pw_desc surface: K 48..510, both weight orientations, two K-panels, head groups, per-image weights,
+    ragged pixel counts.  Integer data: exact up to the final rounding of the store."""
     B = 2
     K = K1 + K2
-    x1 = ints((B, groups * K1, *hw), 91).bfloat16()
-    x2 = ints((B, groups * K2, *hw), 92).bfloat16() if K2 else None
+    x1 = ints((B, groups * K1, *hw), 91).to(dtype)
+    x2 = ints((B, groups * K2, *hw), 92).to(dtype) if K2 else None
     wshape = (B if per_image else 1, groups, M, K)
     w = ints(wshape, 93, -2, 3)
     bias = ints((groups, M), 94)
-    res = ints((B, groups * M, *hw), 95).bfloat16()
+    res = ints((B, groups * M, *hw), 95).to(dtype)
     xs = x1.float().reshape(B, groups, K1, -1)
     if K2:
         xs = torch.cat([xs, x2.float().reshape(B, groups, K2, -1)], 2)
     ref = torch.einsum("bgmk,bgkn->bgmn", w.expand(B, -1, -1, -1), xs) + bias[None, :, :, None]
-    ref = (ref.reshape(B, groups * M, *hw) + res.float()).bfloat16().float()
+    ref = (ref.reshape(B, groups * M, *hw) + res.float()).to(dtype).float()
     warg = w.transpose(-1, -2).contiguous() if transposed else w
     y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), bias.to(DEV), res.to(DEV), M, groups,
                 per_image, transposed)
