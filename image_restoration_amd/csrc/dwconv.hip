@@ -1,8 +1,13 @@
 // Depthwise k x k convolution on NCHW planes (Restormer.py:84,106; moce_ir.py:341), its
 // transposed (backward-data) form and the weight gradient, with the GDFN GELU gate
 // (Restormer.py:90-91) fused as an output epilogue (forward) or an input prologue (backward).
-// One workgroup = one (image, channel) plane tile staged in LDS with its halo; each thread
-// produces 4 consecutive outputs of one row.  HBM-bound: reads the input once (+halo), writes once.
+//
+// One workgroup = one (image, channel) plane tile staged in LDS with its halo.  256 threads form a
+// TXN x (256/TXN) grid; each thread produces RPT consecutive rows x 4 consecutive pixels with a sliding
+// row window (RPT = 4 on large planes: 64 x 64 outputs per workgroup, ~8 KB of loads in flight per workgroup
+// instead of 2 KB: these kernels are HBM/latency bound and MI355X wants >= 40 KB in flight per CU).
+// Backward computes dx AND the weight/bias gradient partials in ONE pass over (dy, x): the dy tile is staged
+// once and used for both.
 #include "common.h"
 
 namespace mi {
@@ -37,14 +42,6 @@ __device__ __forceinline__ float dw_fetch(const DwArgs& a, int b, int cc, int y,
   }
 }
 
-template <int KS, int TW> struct DwGeom {
-  static constexpr int P = KS / 2;
-  static constexpr int TXN = TW / 4;         // threads along x
-  static constexpr int TH = 256 / TXN;       // tile rows
-  static constexpr int LW = TW + 2 * P + 1;  // LDS row stride (floats)
-  static constexpr int LH = TH + 2 * P;
-};
-
 // 4 consecutive pixels (x..x+3) of plane cc at row y; out-of-image pixels read as 0.  vec_ok: W % 4 == 0 and
 // 16-byte aligned bases, so a 4-group that starts inside the row lies entirely inside it.
 template <typename T, int MODE>
@@ -75,19 +72,54 @@ __device__ __forceinline__ void dw_fetch4(const DwArgs& a, int b, int cc, int y,
   }
 }
 
-// Stage the (TH+2P) x (TW+2P) input tile: the TW interior columns as 4-wide vector loads, the 2P halo columns scalar.
-template <typename T, int KS, int TW, int MODE>
-__device__ __forceinline__ void dw_stage(float* tile, const DwArgs& a, int b, int cc, int y0, int x0, bool vec_ok) {
-  using G = DwGeom<KS, TW>;
-  constexpr int VPR = TW / 4;  // vectors per row
-  for (int e = threadIdx.x; e < G::LH * VPR; e += 256) {
-    const int r = e / VPR, v = e - r * VPR;
+template <int KS, int TW, int RPT> struct DwGeom {
+  static constexpr int P = KS / 2;
+  static constexpr int TXN = TW / 4;              // threads along x
+  static constexpr int TYN = 256 / TXN;           // threads along y
+  static constexpr int TH = TYN * RPT;            // tile rows
+  static constexpr int LW = TW + 2 * P + 1;       // LDS row stride (floats)
+  static constexpr int LH = TH + 2 * P;
+  static constexpr int WIN = RPT + KS - 1;        // input rows a thread touches
+};
+
+// Staging of the (TH+2P) x (TW+2P) input tile is split in two phases so that EVERY vector load of a workgroup's
+// tile(s) is in flight before the first LDS write waits on one: dw_load_vecs (interior columns, 4-wide vectors, fully
+// unrolled) ... dw_write_vecs; the 2P halo columns follow as scalars.
+template <typename G, int TW> struct DwStage {
+  static constexpr int VPR = TW / 4;                          // vectors per row
+  static constexpr int NV = (G::LH * VPR + 255) / 256;        // vectors per thread
+};
+
+template <typename T, typename G, int TW, int MODE>
+__device__ __forceinline__ void dw_load_vecs(const DwArgs& a, int b, int cc, int y0, int x0, bool vec_ok,
+                                             float (*o)[4]) {
+  using S = DwStage<G, TW>;
+#pragma unroll
+  for (int i = 0; i < S::NV; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int r = e / S::VPR, v = e - r * S::VPR;
     const int gy = y0 - G::P + r, gx = x0 + 4 * v;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < a.H && gx < a.W) dw_fetch4<T, MODE>(a, b, cc, gy, gx, vec_ok, o);
-    float* d = tile + r * G::LW + G::P + 4 * v;
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+    o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
+    if (e < G::LH * S::VPR && gy >= 0 && gy < a.H && gx < a.W) dw_fetch4<T, MODE>(a, b, cc, gy, gx, vec_ok, o[i]);
   }
+}
+
+template <typename G, int TW>
+__device__ __forceinline__ void dw_write_vecs(float* tile, const float (*o)[4]) {
+  using S = DwStage<G, TW>;
+#pragma unroll
+  for (int i = 0; i < S::NV; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    if (e < G::LH * S::VPR) {
+      const int r = e / S::VPR, v = e - r * S::VPR;
+      float* d = tile + r * G::LW + G::P + 4 * v;
+      d[0] = o[i][0]; d[1] = o[i][1]; d[2] = o[i][2]; d[3] = o[i][3];
+    }
+  }
+}
+
+template <typename T, typename G, int TW, int MODE>
+__device__ __forceinline__ void dw_stage_halo(float* tile, const DwArgs& a, int b, int cc, int y0, int x0) {
   for (int e = threadIdx.x; e < G::LH * 2 * G::P; e += 256) {
     const int r = e / (2 * G::P), hcol = e - r * (2 * G::P);
     const int c = hcol < G::P ? hcol : TW + hcol;  // left halo cols [0,P), right halo cols [TW+P, TW+2P)
@@ -98,21 +130,28 @@ __device__ __forceinline__ void dw_stage(float* tile, const DwArgs& a, int b, in
   }
 }
 
-template <int KS, int TW, bool FLIP>
-__device__ __forceinline__ void dw_compute(const float* tile, const float* wk, float bias, int ty, int tx, float* o) {
-  using G = DwGeom<KS, TW>;
+// o[r][j] = bias + sum_{ky,kx} w[ky][kx] * tile[RPT*ty + r + ky][4*tx + j + kx]; each input row is read once.
+template <typename G, int KS, int RPT, bool FLIP>
+__device__ __forceinline__ void dw_compute(const float* tile, const float* wk, float bias, int ty, int tx, float (*o)[4]) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = bias;
+  for (int r = 0; r < RPT; ++r)
 #pragma unroll
-  for (int ky = 0; ky < KS; ++ky) {
+    for (int j = 0; j < 4; ++j) o[r][j] = bias;
+#pragma unroll
+  for (int wr = 0; wr < G::WIN; ++wr) {
     float row[4 + KS - 1];
 #pragma unroll
-    for (int i = 0; i < 4 + KS - 1; ++i) row[i] = tile[(ty + ky) * G::LW + 4 * tx + i];
+    for (int i = 0; i < 4 + KS - 1; ++i) row[i] = tile[(RPT * ty + wr) * G::LW + 4 * tx + i];
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
-      const float wv = FLIP ? wk[KS * KS - 1 - (ky * KS + kx)] : wk[ky * KS + kx];
+    for (int r = 0; r < RPT; ++r) {
+      const int ky = wr - r;
+      if (ky < 0 || ky >= KS) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += wv * row[j + kx];
+      for (int kx = 0; kx < KS; ++kx) {
+        const float wv = FLIP ? wk[KS * KS - 1 - (ky * KS + kx)] : wk[ky * KS + kx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[r][j] += wv * row[j + kx];
+      }
     }
   }
 }
@@ -130,11 +169,11 @@ __device__ __forceinline__ void dw_store4(T* plane, int H, int W, int y, int x, 
   }
 }
 
-// forward / backward-data.  GATE: blockIdx.y indexes the hidden channel j; planes j and j+hidden are convolved,
+// forward.  GATE: blockIdx.y indexes the hidden channel j; planes j and j+hidden are convolved,
 // y (optional) gets both, g = gelu(y1)*y2.
-template <typename T, int KS, int TW, int MODE, bool GATE, bool FLIP>
+template <typename T, int KS, int TW, int RPT, bool GATE>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
-  using G = DwGeom<KS, TW>;
+  using G = DwGeom<KS, TW, RPT>;
   __shared__ float tile[(GATE ? 2 : 1) * G::LH * G::LW];
   __shared__ float wsm[(GATE ? 2 : 1) * KS * KS];
   const int tile_id = blockIdx.x;
@@ -145,129 +184,194 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
     wsm[threadIdx.x] = a.w[(int64_t)cc * KS * KS + threadIdx.x];
     if (GATE) wsm[KS * KS + threadIdx.x] = a.w[(int64_t)(cc + a.hidden) * KS * KS + threadIdx.x];
   }
-  dw_stage<T, KS, TW, MODE>(tile, a, b, cc, y0, x0, vec_ok);
-  if (GATE) dw_stage<T, KS, TW, MODE>(tile + G::LH * G::LW, a, b, cc + a.hidden, y0, x0, vec_ok);
+  {
+    float va[DwStage<G, TW>::NV][4], vb[GATE ? DwStage<G, TW>::NV : 1][4];
+    dw_load_vecs<T, G, TW, IN_PLAIN>(a, b, cc, y0, x0, vec_ok, va);
+    if (GATE) dw_load_vecs<T, G, TW, IN_PLAIN>(a, b, cc + a.hidden, y0, x0, vec_ok, vb);
+    dw_write_vecs<G, TW>(tile, va);
+    if (GATE) dw_write_vecs<G, TW>(tile + G::LH * G::LW, vb);
+    dw_stage_halo<T, G, TW, IN_PLAIN>(tile, a, b, cc, y0, x0);
+    if (GATE) dw_stage_halo<T, G, TW, IN_PLAIN>(tile + G::LH * G::LW, a, b, cc + a.hidden, y0, x0);
+  }
   __syncthreads();
   const int64_t HW = (int64_t)a.H * a.W;
-  float o1[4];
-  dw_compute<KS, TW, FLIP>(tile, wsm, a.bias ? a.bias[cc] : 0.f, ty, tx, o1);
-  const int oy = y0 + ty, ox = x0 + 4 * tx;
+  float o1[RPT][4];
+  dw_compute<G, KS, RPT, false>(tile, wsm, a.bias ? a.bias[cc] : 0.f, ty, tx, o1);
+  const int oy = y0 + RPT * ty, ox = x0 + 4 * tx;
   if (!GATE) {
-    dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc) * HW, a.H, a.W, oy, ox, o1, vec_ok);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc) * HW, a.H, a.W, oy + r, ox, o1[r], vec_ok);
   } else {
-    float o2[4], g[4];
-    dw_compute<KS, TW, FLIP>(tile + G::LH * G::LW, wsm + KS * KS, a.bias ? a.bias[cc + a.hidden] : 0.f, ty, tx, o2);
-    if (a.out) {
-      dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc) * HW, a.H, a.W, oy, ox, o1, vec_ok);
-      dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc + a.hidden) * HW, a.H, a.W, oy, ox, o2, vec_ok);
-      // the gate is evaluated on the values as stored (what backward will re-read)
+    float o2[RPT][4];
+    dw_compute<G, KS, RPT, false>(tile + G::LH * G::LW, wsm + KS * KS, a.bias ? a.bias[cc + a.hidden] : 0.f, ty, tx, o2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { o1[j] = to_f32(Cvt<T>::from(o1[j])); o2[j] = to_f32(Cvt<T>::from(o2[j])); }
+    for (int r = 0; r < RPT; ++r) {
+      float g[4];
+      if (a.out) {
+        dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc) * HW, a.H, a.W, oy + r, ox, o1[r], vec_ok);
+        dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + cc + a.hidden) * HW, a.H, a.W, oy + r, ox, o2[r], vec_ok);
+        // the gate is evaluated on the values as stored (what backward will re-read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o1[r][j] = to_f32(Cvt<T>::from(o1[r][j])); o2[r][j] = to_f32(Cvt<T>::from(o2[r][j])); }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = gelu_erf(o1[r][j]) * o2[r][j];
+      dw_store4<T>((T*)a.gate + ((int64_t)b * a.hidden + cc) * HW, a.H, a.W, oy + r, ox, g, vec_ok);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = gelu_erf(o1[j]) * o2[j];
-    dw_store4<T>((T*)a.gate + ((int64_t)b * a.hidden + cc) * HW, a.H, a.W, oy, ox, g, vec_ok);
   }
 }
 
-// weight gradient: dw[c][ky][kx] = sum_{b,y,x} dy[b,c,y,x] * x[b,c,y+ky-P,x+kx-P];  db[c] = sum dy.
-// grid (tiles, Cc); loops over the batch; block partial -> part[tile][Cc*KK | Cc].
-template <typename T, int KS, int TW, int MODE>
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwArgs dya, const T* __restrict__ xin, float* __restrict__ part,
-                                                           int B, int vec_ok) {
-  using G = DwGeom<KS, TW>;
+// Backward: dx = dw^T(dy) (flipped taps over the dy tile) and, from the same staged dy tile plus the x tile,
+//   dW[c][ky][kx] partial = sum_{tile pixels} dy[y][x] * x[y+ky-P][x+kx-P],  db partial = sum dy.
+// grid (tiles, Cc, B); block partial -> part[b*tiles + tile][Cc*KK | Cc].  WANT_DX / WANT_DW select the halves.
+template <typename T, int KS, int TW, int RPT, int MODE, bool WANT_DX, bool WANT_DW>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __restrict__ xin, float* __restrict__ part,
+                                                         int vec_ok) {
+  using G = DwGeom<KS, TW, RPT>;
   constexpr int KK = KS * KS;
-  __shared__ float tile[G::LH * G::LW];
+  constexpr int P = G::P;
+  __shared__ float dyt[G::LH * G::LW];
+  __shared__ float xt[WANT_DW ? G::LH * G::LW : 1];
+  __shared__ float wsm[KK];
   __shared__ float red[4][KK + 1];
-  const int tile_id = blockIdx.x;
+  const int tile_id = blockIdx.x, tiles = gridDim.x;
   const int x0 = (tile_id % dya.tiles_x) * TW, y0 = (tile_id / dya.tiles_x) * G::TH;
-  const int cc = blockIdx.y;
+  const int cc = blockIdx.y, b = blockIdx.z;
   const int tx = threadIdx.x % G::TXN, ty = threadIdx.x / G::TXN;
-  const int oy = y0 + ty, ox = x0 + 4 * tx;
-  DwArgs xa = dya;
-  xa.in = xin;
-  float acc[KK + 1];
-#pragma unroll
-  for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    __syncthreads();
-    dw_stage<T, KS, TW, IN_PLAIN>(tile, xa, b, cc, y0, x0, vec_ok);
-    float d[4] = {0.f, 0.f, 0.f, 0.f};
-    if (oy < dya.H && ox < dya.W) dw_fetch4<T, MODE>(dya, b, cc, oy, ox, vec_ok, d);
-    __syncthreads();
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky) {
-      float row[4 + KS - 1];
-#pragma unroll
-      for (int i = 0; i < 4 + KS - 1; ++i) row[i] = tile[(ty + ky) * G::LW + 4 * tx + i];
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ky * KS + kx] += d[j] * row[j + kx];
-    }
-    acc[KK] += (d[0] + d[1]) + (d[2] + d[3]);
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i <= KK; ++i) {
-    const float s = wave_sum(acc[i]);
-    if (lane == 0) red[wv][i] = s;
+  const int oy = y0 + RPT * ty, ox = x0 + 4 * tx;
+  if (threadIdx.x < KK) wsm[threadIdx.x] = dya.w[(int64_t)cc * KK + threadIdx.x];
+  {
+    DwArgs xa = dya;
+    xa.in = xin;
+    float va[DwStage<G, TW>::NV][4], vb[WANT_DW ? DwStage<G, TW>::NV : 1][4];
+    dw_load_vecs<T, G, TW, MODE>(dya, b, cc, y0, x0, vec_ok, va);
+    if (WANT_DW) dw_load_vecs<T, G, TW, IN_PLAIN>(xa, b, cc, y0, x0, vec_ok, vb);
+    dw_write_vecs<G, TW>(dyt, va);
+    if (WANT_DW) dw_write_vecs<G, TW>(xt, vb);
+    dw_stage_halo<T, G, TW, MODE>(dyt, dya, b, cc, y0, x0);
+    if (WANT_DW) dw_stage_halo<T, G, TW, IN_PLAIN>(xt, xa, b, cc, y0, x0);
   }
   __syncthreads();
-  if (threadIdx.x <= KK) {
-    const int i = threadIdx.x;
-    const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-    float* prow = part + (int64_t)tile_id * ((int64_t)dya.Cc * (KK + 1));
-    if (i < KK) prow[(int64_t)cc * KK + i] = s;
-    else prow[(int64_t)dya.Cc * KK + cc] = s;
+  if (WANT_DX) {
+    float o[RPT][4];
+    dw_compute<G, KS, RPT, true>(dyt, wsm, 0.f, ty, tx, o);
+    const int64_t HW = (int64_t)dya.H * dya.W;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      dw_store4<T>((T*)dya.out + ((int64_t)b * dya.Cc + cc) * HW, dya.H, dya.W, oy + r, ox, o[r], vec_ok);
+  }
+  if (WANT_DW) {
+    float acc[KK + 1];
+#pragma unroll
+    for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
+    // the thread's dy values (tile centre; out-of-image entries of the staged tile are already zero)
+    float d[RPT][4];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d[r][j] = dyt[(RPT * ty + r + P) * G::LW + 4 * tx + j + P];
+        acc[KK] += d[r][j];
+      }
+#pragma unroll
+    for (int wr = 0; wr < G::WIN; ++wr) {
+      float row[4 + KS - 1];
+#pragma unroll
+      for (int i = 0; i < 4 + KS - 1; ++i) row[i] = xt[(RPT * ty + wr) * G::LW + 4 * tx + i];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int ky = wr - r;
+        if (ky < 0 || ky >= KS) continue;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ky * KS + kx] += d[r][j] * row[j + kx];
+      }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i <= KK; ++i) {
+      const float s = wave_sum(acc[i]);
+      if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x <= KK) {
+      const int i = threadIdx.x;
+      const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+      float* prow = part + ((int64_t)b * tiles + tile_id) * ((int64_t)dya.Cc * (KK + 1));
+      if (i < KK) prow[(int64_t)cc * KK + i] = s;
+      else prow[(int64_t)dya.Cc * KK + cc] = s;
+    }
   }
 }
 
-static int pick_tw(int W) { return W >= 48 ? 64 : (W >= 24 ? 32 : 16); }
+struct DwTiling { int tw, rpt, th, tiles_x, tiles; };
+static DwTiling dw_tiling(int H, int W, int ks) {
+  DwTiling t;
+  t.tw = W >= 48 ? 64 : (W >= 24 ? 32 : 16);
+  const int tyn = 256 / (t.tw / 4);
+  t.rpt = (ks == 3 && H >= 2 * tyn) ? 4 : 1;  // tall tiles for 3x3 where the plane has the rows for them
+  t.th = tyn * t.rpt;
+  t.tiles_x = cdiv(W, t.tw);
+  t.tiles = t.tiles_x * cdiv(H, t.th);
+  return t;
+}
 
-template <typename T, int KS, int MODE, bool GATE, bool FLIP>
+#define DW_TILE_SWITCH(LAUNCH)                                                                         \
+  do {                                                                                                 \
+    constexpr int R4 = KS == 3 ? 4 : 1; /* RPT=4 instantiated for 3x3 only (dw_tiling never picks it otherwise) */ \
+    if (tl.tw == 64) { if (tl.rpt == 4) { LAUNCH(64, R4); } else { LAUNCH(64, 1); } }                   \
+    else if (tl.tw == 32) { if (tl.rpt == 4) { LAUNCH(32, R4); } else { LAUNCH(32, 1); } }              \
+    else { if (tl.rpt == 4) { LAUNCH(16, R4); } else { LAUNCH(16, 1); } }                               \
+  } while (0)
+
+template <typename T, int KS, bool GATE>
 static int dw_launch(DwArgs a, int B, hipStream_t st) {
-  const int tw = pick_tw(a.W);
-  const int th = 256 / (tw / 4);
-  a.tiles_x = cdiv(a.W, tw);
-  const int tiles = a.tiles_x * cdiv(a.H, th);
-  const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate) && aligned16(a.in) && aligned16(a.gy);
-  dim3 grid(tiles, GATE ? a.hidden : a.Cc, B), block(256);
+  const DwTiling tl = dw_tiling(a.H, a.W, KS);
+  a.tiles_x = tl.tiles_x;
+  const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate) && aligned16(a.in);
+  dim3 grid(tl.tiles, GATE ? a.hidden : a.Cc, B), block(256);
   const double plane = (double)B * a.H * a.W * sizeof(T);
-  const int kid = GATE ? K_DW_GATE_FWD : (FLIP ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_FWD);
-  const double chans = GATE ? (a.Cc + (a.out ? a.Cc : 0) + a.hidden)
-                            : (MODE == IN_GATE_BWD ? (a.hidden + 2.0 * a.Cc) : 2.0 * a.Cc);
-  ProfScope ps(st, kid, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
-  if (tw == 64) hipLaunchKernelGGL((dwconv_kernel<T, KS, 64, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
-  else if (tw == 32) hipLaunchKernelGGL((dwconv_kernel<T, KS, 32, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
-  else hipLaunchKernelGGL((dwconv_kernel<T, KS, 16, MODE, GATE, FLIP>), grid, block, 0, st, a, vec_ok);
+  const double chans = GATE ? (a.Cc + (a.out ? a.Cc : 0) + a.hidden) : 2.0 * a.Cc;
+  ProfScope ps(st, GATE ? K_DW_GATE_FWD : K_DW_FWD, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
+#define DW_FWD_LAUNCH(TWV, RPTV) \
+  hipLaunchKernelGGL((dwconv_kernel<T, KS, TWV, RPTV, GATE>), grid, block, 0, st, a, vec_ok)
+  DW_TILE_SWITCH(DW_FWD_LAUNCH);
+#undef DW_FWD_LAUNCH
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
 
 template <typename T, int KS, int MODE>
-static int dw_wgrad_launch(DwArgs dya, const void* xin, float* part, int B, int* tiles_out, hipStream_t st) {
-  const int tw = pick_tw(dya.W);
-  const int th = 256 / (tw / 4);
-  dya.tiles_x = cdiv(dya.W, tw);
-  const int tiles = dya.tiles_x * cdiv(dya.H, th);
-  *tiles_out = tiles;
-  dim3 grid(tiles, dya.Cc), block(256);
-  const int vec_ok = (dya.W % 4 == 0) && aligned16(dya.in) && aligned16(dya.gy) && aligned16(xin);
+static int dw_bwd_launch(DwArgs dya, const void* xin, float* part, int B, bool want_dx, bool want_dw, int* rows_out,
+                         hipStream_t st) {
+  const DwTiling tl = dw_tiling(dya.H, dya.W, KS);
+  dya.tiles_x = tl.tiles_x;
+  *rows_out = tl.tiles * B;
+  const int vec_ok = (dya.W % 4 == 0) && aligned16(dya.in) && aligned16(dya.gy) && aligned16(xin) && aligned16(dya.out);
+  dim3 grid(tl.tiles, dya.Cc, B), block(256);
   const double plane = (double)B * dya.H * dya.W * sizeof(T);
-  ProfScope ps(st, K_DW_WGRAD, (MODE == IN_GATE_BWD ? dya.hidden + 2.0 * dya.Cc : 2.0 * dya.Cc) * plane,
-               2.0 * KS * KS * dya.Cc * (double)B * dya.H * dya.W);
-  if (tw == 64) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 64, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
-  else if (tw == 32) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 32, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
-  else hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KS, 16, MODE>), grid, block, 0, st, dya, (const T*)xin, part, B, vec_ok);
+  const double in_ch = MODE == IN_GATE_BWD ? dya.hidden + (double)dya.Cc : (double)dya.Cc;
+  const int kid = want_dx ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_WGRAD;
+  ProfScope ps(st, kid, (in_ch + (want_dw ? dya.Cc : 0) + (want_dx ? dya.Cc : 0)) * plane,
+               ((want_dx ? 2.0 : 0.0) + (want_dw ? 2.0 : 0.0)) * KS * KS * dya.Cc * (double)B * dya.H * dya.W);
+#define DW_BWD_LAUNCH(TWV, RPTV)                                                                                          \
+  do {                                                                                                                    \
+    if (want_dx && want_dw)                                                                                               \
+      hipLaunchKernelGGL((dwconv_bwd_kernel<T, KS, TWV, RPTV, MODE, true, true>), grid, block, 0, st, dya, (const T*)xin, \
+                         part, vec_ok);                                                                                   \
+    else if (want_dx)                                                                                                     \
+      hipLaunchKernelGGL((dwconv_bwd_kernel<T, KS, TWV, RPTV, MODE, true, false>), grid, block, 0, st, dya,               \
+                         (const T*)xin, part, vec_ok);                                                                    \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((dwconv_bwd_kernel<T, KS, TWV, RPTV, MODE, false, true>), grid, block, 0, st, dya,               \
+                         (const T*)xin, part, vec_ok);                                                                    \
+  } while (0)
+  DW_TILE_SWITCH(DW_BWD_LAUNCH);
+#undef DW_BWD_LAUNCH
   MI_LAUNCH_CHECK();
   return MI_OK;
-}
-
-static int dw_tiles(int H, int W) {
-  const int tw = pick_tw(W);
-  const int th = 256 / (tw / 4);
-  return cdiv(W, tw) * cdiv(H, th);
 }
 
 static int check_common(const char* who, int B, int C, int H, int W, int ks, int dtype) {
@@ -303,7 +407,7 @@ extern "C" int mi_dwconv_fwd(const void* x, const float* w, const float* bias, v
   MI_TRY(check_common("dwconv_fwd", B, C, H, W, ks, dtype));
   DwArgs a{x, nullptr, w, bias, y, nullptr, C, H, W, 0, 0};
   int rc = MI_OK;
-  DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, IN_PLAIN, false, false>(a, B, (hipStream_t)stream)));
+  DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, false>(a, B, (hipStream_t)stream)));
   return rc;
 }
 
@@ -314,37 +418,36 @@ extern "C" int mi_dwconv_gate_fwd(const void* x, const float* w, const float* bi
   MI_TRY(check_common("dwconv_gate_fwd", B, C2, H, W, ks, dtype));
   DwArgs a{x, nullptr, w, bias, y, g, C2, H, W, C2 / 2, 0};
   int rc = MI_OK;
-  DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, IN_PLAIN, true, false>(a, B, (hipStream_t)stream)));
+  DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, true>(a, B, (hipStream_t)stream)));
   return rc;
 }
 
 extern "C" size_t mi_dwconv_bwd_workspace(int B, int C, int H, int W, int ks) {
-  (void)B;
-  if (H <= 0 || W <= 0 || C <= 0) return 0;
-  return align_up((size_t)dw_tiles(H, W) * C * (ks * ks + 1) * sizeof(float), 256);
+  if (H <= 0 || W <= 0 || C <= 0 || B <= 0) return 0;
+  const DwTiling tl = dw_tiling(H, W, ks);
+  const size_t cols = (size_t)C * (ks * ks + 1);
+  return align_up(((size_t)tl.tiles * B + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
 }
 
 static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, const float* w, void* dx, float* dwg,
                          float* dbg, int B, int Cc, int H, int W, int ks, int accumulate, int dtype, void* ws, int gate,
                          hipStream_t st) {
   DwArgs a{dy_or_dg, gy, w, nullptr, dx, nullptr, Cc, H, W, gate ? Cc / 2 : 0, 0};
-  int rc = MI_OK;
-  if (dx) {
-    if (gate) DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, IN_GATE_BWD, false, true>(a, B, st)));
-    else DW_DISPATCH(T, KS, (rc = dw_launch<T, KS, IN_PLAIN, false, true>(a, B, st)));
-    if (rc != MI_OK) return rc;
-  }
+  MI_CHECK_ARG(dx || dwg, "dwconv_bwd: nothing to compute");
+  MI_CHECK_ARG(!dwg || (ws && x), "dwconv_bwd: weight gradient needs x and a workspace");
+  int rc = MI_OK, rows = 0;
+  float* part = (float*)ws;
+  if (gate) DW_DISPATCH(T, KS, (rc = dw_bwd_launch<T, KS, IN_GATE_BWD>(a, x, part, B, dx != nullptr, dwg != nullptr, &rows, st)));
+  else DW_DISPATCH(T, KS, (rc = dw_bwd_launch<T, KS, IN_PLAIN>(a, x, part, B, dx != nullptr, dwg != nullptr, &rows, st)));
+  if (rc != MI_OK) return rc;
   if (dwg) {
-    MI_CHECK_ARG(ws && x, "dwconv_bwd: weight gradient needs x and a workspace");
-    int tiles = 0;
-    float* part = (float*)ws;
-    if (gate) DW_DISPATCH(T, KS, (rc = dw_wgrad_launch<T, KS, IN_GATE_BWD>(a, x, part, B, &tiles, st)));
-    else DW_DISPATCH(T, KS, (rc = dw_wgrad_launch<T, KS, IN_PLAIN>(a, x, part, B, &tiles, st)));
-    if (rc != MI_OK) return rc;
     const int kk = ks * ks;
     const int64_t ld = (int64_t)Cc * (kk + 1);
-    MI_TRY(launch_reduce_rows(part, dwg, tiles, (int64_t)Cc * kk, ld, accumulate, 1.0f, st));
-    if (dbg) MI_TRY(launch_reduce_rows(part + (int64_t)Cc * kk, dbg, tiles, Cc, ld, accumulate, 1.0f, st));
+    float* tmp = part + (int64_t)rows * ld;
+    MI_TRY(launch_reduce_rows(part, dwg, rows, (int64_t)Cc * kk, ld, accumulate, 1.0f, st, tmp));
+    if (dbg)
+      MI_TRY(launch_reduce_rows(part + (int64_t)Cc * kk, dbg, rows, Cc, ld, accumulate, 1.0f, st,
+                                tmp + (int64_t)REDUCE_GROUPS * Cc * kk));
   }
   return MI_OK;
 }
