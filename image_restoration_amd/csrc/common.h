@@ -168,11 +168,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact-erf GELU and its derivative (Restormer.py:91: F.gelu default = erf form)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-form GELU and its derivative (Restormer.py:91: F.gelu default = erf form).
+// erf is evaluated with Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): one reciprocal,
+// one exp and five FMAs instead of the ~35-instruction branchy libm erff; exp(-x^2/2) is shared with the Gaussian
+// density of the derivative.  gelu_parts returns cdf = Phi(x) and pdf = phi(x).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float q = 0.5f * poly * e;          // = 0.5 * erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.0f - q : q;
+  pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
   return cdf + x * pdf;
 }
 

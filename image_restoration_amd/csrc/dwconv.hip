@@ -77,7 +77,8 @@ template <int KS, int TW, int RPT> struct DwGeom {
   static constexpr int TXN = TW / 4;              // threads along x
   static constexpr int TYN = 256 / TXN;           // threads along y
   static constexpr int TH = TYN * RPT;            // tile rows
-  static constexpr int LW = TW + 2 * P + 1;       // LDS row stride (floats)
+  static constexpr int LW = (TW + 2 * P + 3) / 4 * 4;  // LDS row stride (floats), multiple of 4: a thread's row window
+                                                     // starts 16-byte aligned at column 4*tx -> ds_read_b128/b64
   static constexpr int LH = TH + 2 * P;
   static constexpr int WIN = RPT + KS - 1;        // input rows a thread touches
 };
@@ -130,6 +131,20 @@ __device__ __forceinline__ void dw_stage_halo(float* tile, const DwArgs& a, int 
   }
 }
 
+// N = KS+3 consecutive floats from a 16-byte aligned LDS address as wide reads (N is even: 6, 8 or 10)
+template <int N>
+__device__ __forceinline__ void dw_window(const float* p, float* row) {
+#pragma unroll
+  for (int i = 0; i + 4 <= N; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    row[i] = v[0]; row[i + 1] = v[1]; row[i + 2] = v[2]; row[i + 3] = v[3];
+  }
+  if (N % 4) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(p + N / 4 * 4);
+    row[N / 4 * 4] = v[0]; row[N / 4 * 4 + 1] = v[1];
+  }
+}
+
 // o[r][j] = bias + sum_{ky,kx} w[ky][kx] * tile[RPT*ty + r + ky][4*tx + j + kx]; each input row is read once.
 template <typename G, int KS, int RPT, bool FLIP>
 __device__ __forceinline__ void dw_compute(const float* tile, const float* wk, float bias, int ty, int tx, float (*o)[4]) {
@@ -140,8 +155,7 @@ __device__ __forceinline__ void dw_compute(const float* tile, const float* wk, f
 #pragma unroll
   for (int wr = 0; wr < G::WIN; ++wr) {
     float row[4 + KS - 1];
-#pragma unroll
-    for (int i = 0; i < 4 + KS - 1; ++i) row[i] = tile[(RPT * ty + wr) * G::LW + 4 * tx + i];
+    dw_window<4 + KS - 1>(&tile[(RPT * ty + wr) * G::LW + 4 * tx], row);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int ky = wr - r;
@@ -174,7 +188,7 @@ __device__ __forceinline__ void dw_store4(T* plane, int H, int W, int y, int x, 
 template <typename T, int KS, int TW, int RPT, bool GATE>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
   using G = DwGeom<KS, TW, RPT>;
-  __shared__ float tile[(GATE ? 2 : 1) * G::LH * G::LW];
+  __shared__ __attribute__((aligned(16))) float tile[(GATE ? 2 : 1) * G::LH * G::LW];
   __shared__ float wsm[(GATE ? 2 : 1) * KS * KS];
   const int tile_id = blockIdx.x;
   const int x0 = (tile_id % a.tiles_x) * TW, y0 = (tile_id / a.tiles_x) * G::TH;
@@ -231,8 +245,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
   using G = DwGeom<KS, TW, RPT>;
   constexpr int KK = KS * KS;
   constexpr int P = G::P;
-  __shared__ float dyt[G::LH * G::LW];
-  __shared__ float xt[WANT_DW ? G::LH * G::LW : 1];
+  __shared__ __attribute__((aligned(16))) float dyt[G::LH * G::LW];
+  __shared__ __attribute__((aligned(16))) float xt[WANT_DW ? G::LH * G::LW : 1];
   __shared__ float wsm[KK];
   __shared__ float red[4][KK + 1];
   const int tile_id = blockIdx.x, tiles = gridDim.x;
@@ -277,8 +291,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
 #pragma unroll
     for (int wr = 0; wr < G::WIN; ++wr) {
       float row[4 + KS - 1];
-#pragma unroll
-      for (int i = 0; i < 4 + KS - 1; ++i) row[i] = xt[(RPT * ty + wr) * G::LW + 4 * tx + i];
+      dw_window<4 + KS - 1>(&xt[(RPT * ty + wr) * G::LW + 4 * tx], row);
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         const int ky = wr - r;
@@ -306,12 +319,170 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
   }
 }
 
+// GDFN gate backward, both halves of a channel pair in ONE workgroup (Restormer.py:90-91 backwards):
+//   d1 = dg * y2 * gelu'(y1)  (gradient of conv output j),   d2 = dg * gelu(y1)  (gradient of conv output j+h)
+// are formed once per pixel from one read of (dg, y1, y2), staged as two dy tiles, and pushed through the transposed
+// depthwise conv of planes j and j+h; the weight/bias gradient partials of both planes come from the same tiles.
+// grid (tiles, hidden, B); LDS holds 4 tiles, so the tile is 2 rows per thread.
+template <typename T, int KS, int TW, int RPT, bool WANT_DW>
+__global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
+                                                              int vec_ok) {
+  using G = DwGeom<KS, TW, RPT>;
+  using S = DwStage<G, TW>;
+  constexpr int KK = KS * KS;
+  constexpr int P = G::P;
+  constexpr int TSZ = G::LH * G::LW;
+  __shared__ __attribute__((aligned(16))) float d1t[TSZ];
+  __shared__ __attribute__((aligned(16))) float d2t[TSZ];
+  __shared__ __attribute__((aligned(16))) float x1t[WANT_DW ? TSZ : 1];
+  __shared__ __attribute__((aligned(16))) float x2t[WANT_DW ? TSZ : 1];
+  __shared__ float wsm[2 * KK];
+  __shared__ float red[4][2 * (KK + 1)];
+  const int tile_id = blockIdx.x, tiles = gridDim.x;
+  const int x0 = (tile_id % a.tiles_x) * TW, y0 = (tile_id / a.tiles_x) * G::TH;
+  const int j = blockIdx.y, b = blockIdx.z, h = a.hidden;
+  const int tx = threadIdx.x % G::TXN, ty = threadIdx.x / G::TXN;
+  const int oy = y0 + RPT * ty, ox = x0 + 4 * tx;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const T* dgp = (const T*)a.in + ((int64_t)b * h + j) * HW;
+  const T* y1p = (const T*)a.gy + ((int64_t)b * a.Cc + j) * HW;
+  const T* y2p = y1p + (int64_t)h * HW;
+  const T* x1p = xin + ((int64_t)b * a.Cc + j) * HW;
+  const T* x2p = x1p + (int64_t)h * HW;
+  if (threadIdx.x < KK) {
+    wsm[threadIdx.x] = a.w[(int64_t)j * KK + threadIdx.x];
+    wsm[KK + threadIdx.x] = a.w[(int64_t)(j + h) * KK + threadIdx.x];
+  }
+  auto ld4 = [&](const T* plane, int gy, int gx, float* o) {
+    if (vec_ok && gx + 3 < a.W) {
+      Vec<T, 4>::ld(plane + (int64_t)gy * a.W + gx, o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = gx + e < a.W ? ld1(plane + (int64_t)gy * a.W + gx + e) : 0.f;
+    }
+  };
+  {  // interior columns: all vector loads first, then the gate math and the LDS writes
+    float vdg[S::NV][4], vy1[S::NV][4], vy2[S::NV][4], vx1[WANT_DW ? S::NV : 1][4], vx2[WANT_DW ? S::NV : 1][4];
+#pragma unroll
+    for (int i = 0; i < S::NV; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int r = e / S::VPR, v = e - r * S::VPR;
+      const int gy = y0 - P + r, gx = x0 + 4 * v;
+      const bool in = e < G::LH * S::VPR && gy >= 0 && gy < a.H && gx < a.W;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { vdg[i][q] = 0.f; vy1[i][q] = 0.f; vy2[i][q] = 0.f; }
+      if (WANT_DW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx1[i][q] = 0.f; vx2[i][q] = 0.f; }
+      }
+      if (in) {
+        ld4(dgp, gy, gx, vdg[i]); ld4(y1p, gy, gx, vy1[i]); ld4(y2p, gy, gx, vy2[i]);
+        if (WANT_DW) { ld4(x1p, gy, gx, vx1[i]); ld4(x2p, gy, gx, vx2[i]); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < S::NV; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < G::LH * S::VPR) {
+        const int r = e / S::VPR, v = e - r * S::VPR;
+        const int o = r * G::LW + P + 4 * v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float cdf, pdf;
+          gelu_parts(vy1[i][q], cdf, pdf);
+          d1t[o + q] = vdg[i][q] * vy2[i][q] * (cdf + vy1[i][q] * pdf);
+          d2t[o + q] = vdg[i][q] * vy1[i][q] * cdf;
+          if (WANT_DW) { x1t[o + q] = vx1[i][q]; x2t[o + q] = vx2[i][q]; }
+        }
+      }
+    }
+  }
+  for (int e = threadIdx.x; e < G::LH * 2 * P; e += 256) {  // halo columns
+    const int r = e / (2 * P), hcol = e - r * (2 * P);
+    const int c = hcol < P ? hcol : TW + hcol;
+    const int gy = y0 - P + r, gx = x0 - P + c;
+    float v1 = 0.f, v2 = 0.f, xa = 0.f, xb = 0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const int64_t pix = (int64_t)gy * a.W + gx;
+      const float dg = ld1(dgp + pix), y1 = ld1(y1p + pix), y2 = ld1(y2p + pix);
+      float cdf, pdf;
+      gelu_parts(y1, cdf, pdf);
+      v1 = dg * y2 * (cdf + y1 * pdf);
+      v2 = dg * y1 * cdf;
+      if (WANT_DW) { xa = ld1(x1p + pix); xb = ld1(x2p + pix); }
+    }
+    d1t[r * G::LW + c] = v1;
+    d2t[r * G::LW + c] = v2;
+    if (WANT_DW) { x1t[r * G::LW + c] = xa; x2t[r * G::LW + c] = xb; }
+  }
+  __syncthreads();
+  if (a.out) {
+    float o[RPT][4];
+    dw_compute<G, KS, RPT, true>(d1t, wsm, 0.f, ty, tx, o);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + j) * HW, a.H, a.W, oy + r, ox, o[r], vec_ok);
+    dw_compute<G, KS, RPT, true>(d2t, wsm + KK, 0.f, ty, tx, o);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + j + h) * HW, a.H, a.W, oy + r, ox, o[r], vec_ok);
+  }
+  if (WANT_DW) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const float* dyt = pl ? d2t : d1t;
+      const float* xt = pl ? x2t : x1t;
+      float acc[KK + 1];
+#pragma unroll
+      for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
+      float d[RPT][4];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d[r][q] = dyt[(RPT * ty + r + P) * G::LW + 4 * tx + q + P];
+          acc[KK] += d[r][q];
+        }
+#pragma unroll
+      for (int wr = 0; wr < G::WIN; ++wr) {
+        float row[4 + KS - 1];
+        dw_window<4 + KS - 1>(&xt[(RPT * ty + wr) * G::LW + 4 * tx], row);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const int ky = wr - r;
+          if (ky < 0 || ky >= KS) continue;
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[ky * KS + kx] += d[r][q] * row[q + kx];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i <= KK; ++i) {
+        const float sres = wave_sum(acc[i]);
+        if (lane == 0) red[wv][pl * (KK + 1) + i] = sres;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * (KK + 1)) {
+      const int pl = threadIdx.x / (KK + 1), i = threadIdx.x - pl * (KK + 1);
+      const int cc = pl ? j + h : j;
+      const int k = threadIdx.x;
+      const float sres = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      float* prow = part + ((int64_t)b * tiles + tile_id) * ((int64_t)a.Cc * (KK + 1));
+      if (i < KK) prow[(int64_t)cc * KK + i] = sres;
+      else prow[(int64_t)a.Cc * KK + cc] = sres;
+    }
+  }
+}
+
 struct DwTiling { int tw, rpt, th, tiles_x, tiles; };
-static DwTiling dw_tiling(int H, int W, int ks) {
+static DwTiling dw_tiling(int H, int W, int ks, int max_rpt = 4) {
   DwTiling t;
   t.tw = W >= 48 ? 64 : (W >= 24 ? 32 : 16);
   const int tyn = 256 / (t.tw / 4);
-  t.rpt = (ks == 3 && H >= 2 * tyn) ? 4 : 1;  // tall tiles for 3x3 where the plane has the rows for them
+  t.rpt = (ks == 3 && H >= 2 * tyn) ? max_rpt : 1;  // tall tiles for 3x3 where the plane has the rows for them
   t.th = tyn * t.rpt;
   t.tiles_x = cdiv(W, t.tw);
   t.tiles = t.tiles_x * cdiv(H, t.th);
@@ -328,7 +499,8 @@ static DwTiling dw_tiling(int H, int W, int ks) {
 
 template <typename T, int KS, bool GATE>
 static int dw_launch(DwArgs a, int B, hipStream_t st) {
-  const DwTiling tl = dw_tiling(a.H, a.W, KS);
+  constexpr int RMAX = KS == 3 ? (GATE ? 2 : 4) : 1;  // the gate form holds two tiles and two accumulator sets: 2 rows/thread
+  const DwTiling tl = dw_tiling(a.H, a.W, KS, RMAX);
   a.tiles_x = tl.tiles_x;
   const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate) && aligned16(a.in);
   dim3 grid(tl.tiles, GATE ? a.hidden : a.Cc, B), block(256);
@@ -337,7 +509,9 @@ static int dw_launch(DwArgs a, int B, hipStream_t st) {
   ProfScope ps(st, GATE ? K_DW_GATE_FWD : K_DW_FWD, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
 #define DW_FWD_LAUNCH(TWV, RPTV) \
   hipLaunchKernelGGL((dwconv_kernel<T, KS, TWV, RPTV, GATE>), grid, block, 0, st, a, vec_ok)
-  DW_TILE_SWITCH(DW_FWD_LAUNCH);
+  if (tl.tw == 64) { if (tl.rpt > 1) DW_FWD_LAUNCH(64, RMAX); else DW_FWD_LAUNCH(64, 1); }
+  else if (tl.tw == 32) { if (tl.rpt > 1) DW_FWD_LAUNCH(32, RMAX); else DW_FWD_LAUNCH(32, 1); }
+  else { if (tl.rpt > 1) DW_FWD_LAUNCH(16, RMAX); else DW_FWD_LAUNCH(16, 1); }
 #undef DW_FWD_LAUNCH
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -370,6 +544,35 @@ static int dw_bwd_launch(DwArgs dya, const void* xin, float* part, int B, bool w
   } while (0)
   DW_TILE_SWITCH(DW_BWD_LAUNCH);
 #undef DW_BWD_LAUNCH
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+template <typename T, int KS>
+static int dw_gate_bwd_launch(DwArgs a, const void* xin, float* part, int B, bool want_dw, int* rows_out, hipStream_t st) {
+  const DwTiling tl = dw_tiling(a.H, a.W, KS, 2);
+  a.tiles_x = tl.tiles_x;
+  *rows_out = tl.tiles * B;
+  const int vec_ok = (a.W % 4 == 0) && aligned16(a.in) && aligned16(a.gy) && aligned16(xin) && aligned16(a.out);
+  dim3 grid(tl.tiles, a.hidden, B), block(256);
+  const double plane = (double)B * a.H * a.W * sizeof(T);
+  ProfScope ps(st, a.out ? K_DW_GATE_BWD_DATA : K_DW_WGRAD,
+               (a.hidden + (double)a.Cc + (want_dw ? a.Cc : 0) + (a.out ? a.Cc : 0)) * plane,
+               ((a.out ? 2.0 : 0.0) + (want_dw ? 2.0 : 0.0)) * KS * KS * a.Cc * (double)B * a.H * a.W);
+#define DW_GB_LAUNCH(TWV, RPTV)                                                                                       \
+  do {                                                                                                                \
+    if (want_dw)                                                                                                      \
+      hipLaunchKernelGGL((dwconv_gate_bwd_kernel<T, KS, TWV, RPTV, true>), grid, block, 0, st, a, (const T*)xin, part, \
+                         vec_ok);                                                                                     \
+    else                                                                                                              \
+      hipLaunchKernelGGL((dwconv_gate_bwd_kernel<T, KS, TWV, RPTV, false>), grid, block, 0, st, a, (const T*)xin, part, \
+                         vec_ok);                                                                                     \
+  } while (0)
+  constexpr int R2 = KS == 3 ? 2 : 1;
+  if (tl.tw == 64) { if (tl.rpt == 2) DW_GB_LAUNCH(64, R2); else DW_GB_LAUNCH(64, 1); }
+  else if (tl.tw == 32) { if (tl.rpt == 2) DW_GB_LAUNCH(32, R2); else DW_GB_LAUNCH(32, 1); }
+  else { if (tl.rpt == 2) DW_GB_LAUNCH(16, R2); else DW_GB_LAUNCH(16, 1); }
+#undef DW_GB_LAUNCH
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -424,7 +627,7 @@ extern "C" int mi_dwconv_gate_fwd(const void* x, const float* w, const float* bi
 
 extern "C" size_t mi_dwconv_bwd_workspace(int B, int C, int H, int W, int ks) {
   if (H <= 0 || W <= 0 || C <= 0 || B <= 0) return 0;
-  const DwTiling tl = dw_tiling(H, W, ks);
+  const DwTiling tl = dw_tiling(H, W, ks, 2);  // the gate backward uses the smaller (2 rows/thread) tiles: upper bound
   const size_t cols = (size_t)C * (ks * ks + 1);
   return align_up(((size_t)tl.tiles * B + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
 }
@@ -437,7 +640,7 @@ static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, co
   MI_CHECK_ARG(!dwg || (ws && x), "dwconv_bwd: weight gradient needs x and a workspace");
   int rc = MI_OK, rows = 0;
   float* part = (float*)ws;
-  if (gate) DW_DISPATCH(T, KS, (rc = dw_bwd_launch<T, KS, IN_GATE_BWD>(a, x, part, B, dx != nullptr, dwg != nullptr, &rows, st)));
+  if (gate) DW_DISPATCH(T, KS, (rc = dw_gate_bwd_launch<T, KS>(a, x, part, B, dwg != nullptr, &rows, st)));
   else DW_DISPATCH(T, KS, (rc = dw_bwd_launch<T, KS, IN_PLAIN>(a, x, part, B, dx != nullptr, dwg != nullptr, &rows, st)));
   if (rc != MI_OK) return rc;
   if (dwg) {

@@ -227,61 +227,73 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restri
   }
 }
 
-static void ln_bwd_grid(int B, int64_t N, int vec, int* tiles_img, int* tpb, int* gx) {
-  const int tile = 64 * vec;
-  *tiles_img = cdiv(N, tile);
-  (void)B;
-  *tpb = 1;
-  *gx = cdiv(*tiles_img, *tpb);
+// Shape -> (waves W, channels per thread CPT, pixels per lane VEC).  W*CPT >= C.  Measured on MI355X: wider per-lane
+// vectors (8 or 16 bytes) LOSE here (ln_fwd C=48: 27 -> 40 us) because the extra registers cut the resident
+// workgroups per CU, and these kernels live on bytes in flight; so bf16 keeps 2 pixels (one dword) per lane.
+struct LnCfg { int waves, cpt, vec; };
+static LnCfg ln_cfg(int C, bool bwd, bool f32) {
+  const int v = f32 ? 1 : 2;
+  LnCfg c;
+  if (C <= 16) c = {8, 2, v};
+  else if (C <= 48) c = {8, 6, v};
+  else if (C <= 96) c = {8, 12, v};
+  else if (C <= 192) c = {8, 24, v};
+  else if (C <= 384) c = {16, 24, bwd ? 1 : v};
+  else c = {16, 48, 1};
+  return c;
+}
+static bool ln_aligned(int vec, size_t es, int64_t N, const void* a, const void* b, const void* c, const void* d) {
+  const uintptr_t m = (uintptr_t)vec * es - 1;
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                         reinterpret_cast<uintptr_t>(d);
+  return N % vec == 0 && (bits & m) == 0;
 }
 
-// (waves, channels per thread): C <= 8*{2,6,12,24} with 8 waves, C <= 16*24 = 384 with 16 waves, 16*48 = 768 beyond.
-template <typename T, int VEC, bool WB>
+template <typename T, bool WB>
 static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, float* mean, float* rstd, int B, int C,
                            int64_t N, hipStream_t st) {
-  dim3 grid(cdiv(N, 64 * VEC), B);
+  constexpr bool F32 = sizeof(T) == 4;
+  LnCfg cf = ln_cfg(C, false, F32);
+  if (C > 768) { set_error("ln_fwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
+  if (!ln_aligned(cf.vec, sizeof(T), N, x, y, nullptr, nullptr)) cf.vec = 1;
+  dim3 grid(cdiv(N, 64 * cf.vec), B);
   ProfScope ps(st, K_LN_FWD, 2.0 * B * C * N * sizeof(T) + (mean ? 8.0 * B * N : 0.0), 8.0 * B * C * N);
-#define LN_FWD_CASE(WV, CPT)                                                                                         \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, WV, CPT, VEC, WB>), grid, dim3(64 * WV), 0, st, x, w, b, y, mean, rstd, C, N)
-  if (C <= 16) LN_FWD_CASE(8, 2);
-  else if (C <= 48) LN_FWD_CASE(8, 6);
-  else if (C <= 96) LN_FWD_CASE(8, 12);
-  else if (C <= 192) LN_FWD_CASE(8, 24);
-  else if (C <= 384) LN_FWD_CASE(16, 24);
-  else if (C <= 768) LN_FWD_CASE(16, 48);
-  else { set_error("ln_fwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
+#define LN_FWD_CASE(WV, CPT, VEC)                                                                                   \
+  if (cf.waves == WV && cf.cpt == CPT && cf.vec == VEC)                                                                 \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, WV, CPT, VEC, WB>), grid, dim3(64 * WV), 0, st, x, w, b, y, mean, rstd, C, N)
+  if constexpr (!F32) {
+    LN_FWD_CASE(8, 2, 2); LN_FWD_CASE(8, 6, 2); LN_FWD_CASE(8, 12, 2); LN_FWD_CASE(8, 24, 2); LN_FWD_CASE(16, 24, 2);
+  }
+  LN_FWD_CASE(8, 2, 1); LN_FWD_CASE(8, 6, 1); LN_FWD_CASE(8, 12, 1); LN_FWD_CASE(8, 24, 1); LN_FWD_CASE(16, 24, 1);
+  LN_FWD_CASE(16, 48, 1);
 #undef LN_FWD_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
 
-template <typename T, int VEC, bool WB>
+template <typename T, bool WB>
 static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float* mean, const float* rstd, const T* dres,
-                           T* dx, float* part, int B, int C, int64_t N, int gx, int tpb, int tiles_img, hipStream_t st) {
+                           T* dx, float* part, int B, int C, int64_t N, int* rows_out, hipStream_t st) {
+  constexpr bool F32 = sizeof(T) == 4;
+  LnCfg cf = ln_cfg(C, true, F32);
+  if (C > 768) { set_error("ln_bwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
+  if (!ln_aligned(cf.vec, sizeof(T), N, dy, x, dres, dx)) cf.vec = 1;
+  const int gx = cdiv(N, 64 * cf.vec);
+  *rows_out = gx * B;
   dim3 grid(gx, B);
   ProfScope ps(st, K_LN_BWD, (dres ? 4.0 : 3.0) * B * C * N * sizeof(T) + 8.0 * B * N, 16.0 * B * C * N);
-#define LN_BWD_CASE(WV, CPT)                                                                                           \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, WV, CPT, VEC, WB, (CPT >= 24)>), grid, dim3(64 * WV), 0, st, dy, x, w, mean, rstd, dres, dx, part, \
-                     C, N, tpb, tiles_img)
-  if (C <= 16) LN_BWD_CASE(8, 2);
-  else if (C <= 48) LN_BWD_CASE(8, 6);
-  else if (C <= 96) LN_BWD_CASE(8, 12);
-  else if (C <= 192) LN_BWD_CASE(8, 24);
-  else if (C <= 384) LN_BWD_CASE(16, 24);
-  else if (C <= 768) LN_BWD_CASE(16, 48);
-  else { set_error("ln_bwd: C=%d > 768 unsupported", C); return MI_ERR_ARG; }
+#define LN_BWD_CASE(WV, CPT, VEC)                                                                                     \
+  if (cf.waves == WV && cf.cpt == CPT && cf.vec == VEC)                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, WV, CPT, VEC, WB, (CPT >= 24)>), grid, dim3(64 * WV), 0, st, dy, x, w, mean, rstd, \
+                       dres, dx, part, C, N, 1, gx)
+  if constexpr (!F32) {
+    LN_BWD_CASE(8, 2, 2); LN_BWD_CASE(8, 6, 2); LN_BWD_CASE(8, 12, 2); LN_BWD_CASE(8, 24, 2);
+  }
+  LN_BWD_CASE(8, 2, 1); LN_BWD_CASE(8, 6, 1); LN_BWD_CASE(8, 12, 1); LN_BWD_CASE(8, 24, 1); LN_BWD_CASE(16, 24, 1);
+  LN_BWD_CASE(16, 48, 1);
 #undef LN_BWD_CASE
   MI_LAUNCH_CHECK();
   return MI_OK;
-}
-
-// bf16 rows are read two pixels per lane when that is aligned; wide-C backward keeps one pixel per lane so that its
-// per-thread state (2*CPT*VEC values + 2*CPT partial sums) stays inside the 128-VGPR budget of a 16-wave workgroup.
-static int ln_vec(int dtype, int64_t N, const void* a, const void* b, int C = 0, bool bwd = false) {
-  if (dtype != MI_BF16) return 1;
-  if (bwd && C > 192) return 1;
-  const bool ok = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3u) == 0;
-  return ok ? 2 : 1;
 }
 
 }  // namespace mi
@@ -297,24 +309,16 @@ extern "C" int mi_ln_fwd(const void* x, const float* w, const float* b, void* y,
   MI_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or both NULL");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MI_F32) {
-    return with_bias ? ln_fwd_dispatch<float, 1, true>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st)
-                     : ln_fwd_dispatch<float, 1, false>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st);
-  }
-  if (ln_vec(dtype, N, x, y) == 2) {
-    return with_bias ? ln_fwd_dispatch<bf16, 2, true>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st)
-                     : ln_fwd_dispatch<bf16, 2, false>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st);
-  }
-  return with_bias ? ln_fwd_dispatch<bf16, 1, true>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st)
-                   : ln_fwd_dispatch<bf16, 1, false>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st);
+  if (dtype == MI_F32)
+    return with_bias ? ln_fwd_dispatch<float, true>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st)
+                     : ln_fwd_dispatch<float, false>((const float*)x, w, b, (float*)y, mean, rstd, B, C, N, st);
+  return with_bias ? ln_fwd_dispatch<bf16, true>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st)
+                   : ln_fwd_dispatch<bf16, false>((const bf16*)x, w, b, (bf16*)y, mean, rstd, B, C, N, st);
 }
 
 extern "C" size_t mi_ln_bwd_workspace(int B, int C, int64_t N) {
-  int tiles_img, tpb, gx1, gx2;
-  ln_bwd_grid(B, N, 1, &tiles_img, &tpb, &gx1);
-  ln_bwd_grid(B, N, 2, &tiles_img, &tpb, &gx2);
-  const int gx = gx1 > gx2 ? gx1 : gx2;
-  return align_up(((size_t)gx * B + REDUCE_GROUPS) * 2 * C * sizeof(float), 256);
+  // one partial row of 2C floats per 64-pixel tile in the worst case (one pixel per lane), plus the two-stage scratch
+  return align_up(((size_t)cdiv(N, 64) * B + 2 * REDUCE_GROUPS) * 2 * C * sizeof(float), 256);
 }
 
 extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -326,31 +330,21 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
   MI_CHECK_ARG(!with_bias || db, "ln_bwd: with_bias needs db");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  int vec = ln_vec(dtype, N, dy, x, C, true);
-  if (vec == 2 && ln_vec(dtype, N, dx, dres) != 2) vec = 1;
-  int tiles_img, tpb, gx;
-  ln_bwd_grid(B, N, vec, &tiles_img, &tpb, &gx);
   float* part = (float*)ws;
-  int rc;
+  int rows = 0, rc;
   if (dtype == MI_F32) {
-    rc = with_bias ? ln_bwd_dispatch<float, 1, true>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
-                                                     (float*)dx, part, B, C, N, gx, tpb, tiles_img, st)
-                   : ln_bwd_dispatch<float, 1, false>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
-                                                      (float*)dx, part, B, C, N, gx, tpb, tiles_img, st);
-  } else if (vec == 2) {
-    rc = with_bias ? ln_bwd_dispatch<bf16, 2, true>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
-                                                    (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st)
-                   : ln_bwd_dispatch<bf16, 2, false>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
-                                                     (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st);
+    rc = with_bias ? ln_bwd_dispatch<float, true>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
+                                                  (float*)dx, part, B, C, N, &rows, st)
+                   : ln_bwd_dispatch<float, false>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,
+                                                   (float*)dx, part, B, C, N, &rows, st);
   } else {
-    rc = with_bias ? ln_bwd_dispatch<bf16, 1, true>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
-                                                    (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st)
-                   : ln_bwd_dispatch<bf16, 1, false>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
-                                                     (bf16*)dx, part, B, C, N, gx, tpb, tiles_img, st);
+    rc = with_bias ? ln_bwd_dispatch<bf16, true>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                 (bf16*)dx, part, B, C, N, &rows, st)
+                   : ln_bwd_dispatch<bf16, false>((const bf16*)dy, (const bf16*)x, w, mean, rstd, (const bf16*)dres,
+                                                  (bf16*)dx, part, B, C, N, &rows, st);
   }
   if (rc != MI_OK) return rc;
-  const int64_t rows = (int64_t)gx * B;
-  float* tmp = part + rows * 2 * C;  // two-stage scratch: [REDUCE_GROUPS][C] for dw, then the same for db
+  float* tmp = part + (int64_t)rows * 2 * C;  // two-stage scratch: [REDUCE_GROUPS][C] for dw, then the same for db
   MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st, tmp));
   if (with_bias) MI_TRY(launch_reduce_rows(part + C, db, rows, C, 2 * C, accumulate, 1.0f, st, tmp + (size_t)REDUCE_GROUPS * C));
   return MI_OK;
