@@ -13,169 +13,237 @@
 namespace mi {
 
 constexpr float NORM_EPS = 1e-12f;  // F.normalize eps (Restormer.py:121-122)
+constexpr int ATTN_MAX_C = 128;     // 16x16 threads x (up to) 8x8 register tile
+constexpr int ATT_RC = 16;          // rows of W_o / dM handled by one workgroup
 
-constexpr int ATTN_MAX_C = 128;  // 16x16 threads x 8x8 register tile in the backward glue
 static inline int attn_ld(int c) { return c + 1; }
+static inline int attn_ct(int c) { return (c + 15) / 16; }
+static inline int attn_rchunks(int C) { return (C + ATT_RC - 1) / ATT_RC; }
 
-__global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ graw, const float* __restrict__ ss,
-                                                        const float* __restrict__ temperature, const float* __restrict__ wo,
-                                                        float* __restrict__ P, float* __restrict__ A, float* __restrict__ nrm,
-                                                        float* __restrict__ M, int C, int heads, int ld) {
-  extern __shared__ float sm[];  // [c][ld]
-  const int c = C / heads;
-  const int z = blockIdx.x, b = z / heads, h = z - b * heads;
+// cosine, temperature, row softmax of one (image, head) into LDS As[c][ld]; optionally stored to global P/A/nrm
+__device__ __forceinline__ void attn_softmax_to_lds(float* As, int ld, const float* __restrict__ gz,
+                                                    const float* __restrict__ sz, float temp, int c, float* P, float* A,
+                                                    float* nrm) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const float temp = temperature[h];
-  const float* gz = graw + (int64_t)z * c * c;
-  const float* sz = ss + (int64_t)z * 2 * c;
-  for (int e = t; e < 2 * c; e += 256) nrm[(int64_t)z * 2 * c + e] = fmaxf(sqrtf(sz[e]), NORM_EPS);
+  if (nrm)
+    for (int e = t; e < 2 * c; e += 256) nrm[e] = fmaxf(sqrtf(sz[e]), NORM_EPS);
   for (int e = t; e < c * c; e += 256) {
     const int i = e / c, j = e - i * c;
     const float nq = fmaxf(sqrtf(sz[i]), NORM_EPS), nk = fmaxf(sqrtf(sz[c + j]), NORM_EPS);
     const float pv = gz[e] / (nq * nk);
-    P[(int64_t)z * c * c + e] = pv;
-    sm[i * ld + j] = pv * temp;
+    if (P) P[e] = pv;
+    As[i * ld + j] = pv * temp;
   }
   __syncthreads();
   for (int i = wv; i < c; i += 4) {
     float mx = -INFINITY;
-    for (int j = lane; j < c; j += 64) mx = fmaxf(mx, sm[i * ld + j]);
+    for (int j = lane; j < c; j += 64) mx = fmaxf(mx, As[i * ld + j]);
     mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < c; j += 64) {
-      const float ev = expf(sm[i * ld + j] - mx);
-      sm[i * ld + j] = ev;
+      const float ev = expf(As[i * ld + j] - mx);
+      As[i * ld + j] = ev;
       sum += ev;
     }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     for (int j = lane; j < c; j += 64) {
-      const float a = sm[i * ld + j] * inv;
-      sm[i * ld + j] = a;
-      A[(int64_t)z * c * c + i * c + j] = a;
+      const float av = As[i * ld + j] * inv;
+      As[i * ld + j] = av;
+      if (A) A[i * c + j] = av;
     }
   }
   __syncthreads();
-  // M[b][r][h*c+j] = sum_i wo[r][h*c+i] * A[i][j]
-  float* Mb = M + (int64_t)b * C * C;
-  for (int e = t; e < C * c; e += 256) {
-    const int r = e / c, j = e - r * c;
-    const float* wrow = wo + (int64_t)r * C + h * c;
-    float acc = 0.f;
-    for (int i = 0; i < c; ++i) acc += wrow[i] * sm[i * ld + j];
-    Mb[(int64_t)r * C + h * c + j] = acc;
+}
+
+// forward: grid (Z, C/16).  Every workgroup redoes the (cheap) c x c softmax of its (image, head) in LDS and folds 16
+// rows of W_o:  M[b][r][h*c+j] = sum_i W_o[r][h*c+i] A[i][j].  Row-chunk 0 also stores P, A and the norms.
+template <int CT>
+__global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ graw, const float* __restrict__ ss,
+                                                        const float* __restrict__ temperature, const float* __restrict__ wo,
+                                                        float* __restrict__ P, float* __restrict__ A, float* __restrict__ nrm,
+                                                        float* __restrict__ M, int C, int heads, int ld) {
+  extern __shared__ float sm[];
+  const int c = C / heads;
+  float* As = sm;               // [c][ld]
+  float* Wt = As + c * ld;      // [RC][c]
+  const int z = blockIdx.x, b = z / heads, h = z - b * heads;
+  const int r0 = blockIdx.y * ATT_RC;
+  const int t = threadIdx.x, tr = t >> 4, tj = t & 15;
+  for (int e = t; e < ATT_RC * c; e += 256) {
+    const int rr = e / c, col = e - rr * c;
+    Wt[e] = r0 + rr < C ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+  }
+  const bool first = blockIdx.y == 0;
+  attn_softmax_to_lds(As, ld, graw + (int64_t)z * c * c, ss + (int64_t)z * 2 * c, temperature[h], c,
+                      first ? P + (int64_t)z * c * c : nullptr, first ? A + (int64_t)z * c * c : nullptr,
+                      first ? nrm + (int64_t)z * 2 * c : nullptr);
+  float acc[CT];
+#pragma unroll
+  for (int q = 0; q < CT; ++q) acc[q] = 0.f;
+  for (int i = 0; i < c; ++i) {
+    const float w = Wt[tr * c + i];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int j = tj + 16 * q;
+      if (j < c) acc[q] += w * As[i * ld + j];
+    }
+  }
+  const int r = r0 + tr;
+  if (r < C) {
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int j = tj + 16 * q;
+      if (j < c) M[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = acc[q];
+    }
   }
 }
 
-// Backward glue.  256 threads form a 16x16 grid; thread (ti,tj) owns dA/dS entries (ti+16a, tj+16b), a,b < 8
-// (c <= 128), kept in registers.  W_o and dM column blocks stream through LDS in RC-row chunks (coalesced rows
-// of c floats), A stays in LDS for the whole kernel.
-constexpr int ATT_RC = 16;
-__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ dM, const float* __restrict__ A,
-                                                             const float* __restrict__ P, const float* __restrict__ nrm,
-                                                             const float* __restrict__ temperature,
-                                                             const float* __restrict__ wo, float* __restrict__ dwo_part,
-                                                             float* __restrict__ dtemp_part, float* __restrict__ wdq,
-                                                             float* __restrict__ wdk, int C, int heads, int ld) {
+// backward, stage 1: grid (Z, C/16).  For its 16 rows r of W_o and dM (column block of head h):
+//   dA_part[z][chunk][i][j] = sum_r W_o[r][h*c+i] dM[r][h*c+j]      (thread tile CT x CT)
+//   dWo_part[b][r][h*c+i]   = sum_j dM[r][h*c+j] A[i][j]
+template <int CT>
+__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(const float* __restrict__ dM, const float* __restrict__ A,
+                                                               const float* __restrict__ wo, float* __restrict__ dA_part,
+                                                               float* __restrict__ dwo_part, int C, int heads, int ld) {
   extern __shared__ float sm[];
   const int c = C / heads;
-  float* As = sm;                          // [c][ld]
-  float* Wt = As + c * ld;                 // [RC][c]   W_o[r][h*c + i]
-  float* Dt = Wt + ATT_RC * c;             // [RC][c]   dM[r][h*c + j]
-  float* colp = Dt + ATT_RC * c;           // [16][c]   per-ti partial column sums
-  float* rqs = colp + 16 * c;              // [c]
-  float* rks = rqs + c;                    // [c]
-  float* red = rks + c;                    // [4]
+  float* As = sm;                  // [c][ld]
+  float* Wt = As + c * ld;         // [RC][c]
+  float* Dt = Wt + ATT_RC * c;     // [RC][c]
   const int z = blockIdx.x, b = z / heads, h = z - b * heads;
+  const int rc = blockIdx.y, r0 = rc * ATT_RC;
+  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+  const float* dMb = dM + (int64_t)b * C * C;
+  const float* Az = A + (int64_t)z * c * c;
+  for (int e = t; e < ATT_RC * c; e += 256) {
+    const int rr = e / c, col = e - rr * c;
+    const bool in = r0 + rr < C;
+    Wt[e] = in ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+    Dt[e] = in ? dMb[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+  }
+  for (int e = t; e < c * c; e += 256) { const int i = e / c; As[i * ld + (e - i * c)] = Az[e]; }
+  __syncthreads();
+  float acc[CT][CT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int q = 0; q < CT; ++q) acc[a][q] = 0.f;
+#pragma unroll 4
+  for (int rr = 0; rr < ATT_RC; ++rr) {
+    float wa[CT], db[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) wa[a] = (ti + 16 * a < c) ? Wt[rr * c + ti + 16 * a] : 0.f;
+#pragma unroll
+    for (int q = 0; q < CT; ++q) db[q] = (tj + 16 * q < c) ? Dt[rr * c + tj + 16 * q] : 0.f;
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+      for (int q = 0; q < CT; ++q) acc[a][q] += wa[a] * db[q];
+  }
+  float* dAp = dA_part + ((int64_t)z * gridDim.y + rc) * c * c;
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int i = ti + 16 * a, j = tj + 16 * q;
+      if (i < c && j < c) dAp[i * c + j] = acc[a][q];
+    }
+  // dWo rows of this chunk: thread (tr = ti, lanes tj over i)
+  float wacc[CT];
+#pragma unroll
+  for (int q = 0; q < CT; ++q) wacc[q] = 0.f;
+  for (int j = 0; j < c; ++j) {
+    const float d = Dt[ti * c + j];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int i = tj + 16 * q;
+      if (i < c) wacc[q] += d * As[i * ld + j];
+    }
+  }
+  const int r = r0 + ti;
+  if (r < C) {
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int i = tj + 16 * q;
+      if (i < c) dwo_part[(int64_t)b * C * C + (int64_t)r * C + h * c + i] = wacc[q];
+    }
+  }
+}
+
+// backward, stage 2: grid (Z).  dA = sum of the chunk partials; softmax backward dS = A (dA - rowdot); d temperature;
+// and the per-image weights of the two gradient GEMMs  dq = G1 k + D1 q,  dk = G1^T q + D2 k  with
+// G1 = temperature dS/(|q_i||k_j|), D1_i = -sum_j dS_ij S_ij/|q_i|^2, D2_j = -sum_i dS_ij S_ij/|k_j|^2.
+template <int CT>
+__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __restrict__ dA_part, int rchunks,
+                                                              const float* __restrict__ A, const float* __restrict__ P,
+                                                              const float* __restrict__ nrm,
+                                                              const float* __restrict__ temperature,
+                                                              float* __restrict__ dtemp_part, float* __restrict__ wdq,
+                                                              float* __restrict__ wdk, int C, int heads) {
+  __shared__ float colp[16 * ATTN_MAX_C];
+  __shared__ float rqs[ATTN_MAX_C], rks[ATTN_MAX_C], red[4];
+  const int c = C / heads;
+  const int z = blockIdx.x, h = z % heads;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int ti = t >> 4, tj = t & 15;
   const float temp = temperature[h];
-  const float* dMb = dM + (int64_t)b * C * C;
   const float* Az = A + (int64_t)z * c * c;
   const float* Pz = P + (int64_t)z * c * c;
   const float* nz = nrm + (int64_t)z * 2 * c;
-  float* dwo = dwo_part + (int64_t)b * C * C;
-
-  for (int e = t; e < c * c; e += 256) { const int i = e / c; As[i * ld + (e - i * c)] = Az[e]; }
-
-  float acc[8][8];
+  const float* dAz = dA_part + (int64_t)z * rchunks * c * c;
+  float acc[CT][CT], av[CT][CT];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < CT; ++a)
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) acc[a][bb] = 0.f;
-
-  for (int r0 = 0; r0 < C; r0 += ATT_RC) {
-    __syncthreads();  // previous chunk fully consumed (and As complete on the first pass)
-    for (int e = t; e < ATT_RC * c; e += 256) {
-      const int rr = e / c, col = e - rr * c;
-      const int r = r0 + rr;
-      Wt[e] = r < C ? wo[(int64_t)r * C + h * c + col] : 0.f;
-      Dt[e] = r < C ? dMb[(int64_t)r * C + h * c + col] : 0.f;
+    for (int q = 0; q < CT; ++q) {
+      const int i = ti + 16 * a, j = tj + 16 * q;
+      acc[a][q] = 0.f;
+      av[a][q] = (i < c && j < c) ? Az[i * c + j] : 0.f;
     }
-    __syncthreads();
-    // dA[i][j] += sum_rr Wt[rr][i] * Dt[rr][j]
-#pragma unroll 4
-    for (int rr = 0; rr < ATT_RC; ++rr) {
-      float wa[8], db[8];
+  for (int rc = 0; rc < rchunks; ++rc) {
 #pragma unroll
-      for (int a = 0; a < 8; ++a) wa[a] = (ti + 16 * a < c) ? Wt[rr * c + ti + 16 * a] : 0.f;
+    for (int a = 0; a < CT; ++a)
 #pragma unroll
-      for (int bb = 0; bb < 8; ++bb) db[bb] = (tj + 16 * bb < c) ? Dt[rr * c + tj + 16 * bb] : 0.f;
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) acc[a][bb] += wa[a] * db[bb];
-    }
-    // dWo_part[b][r][h*c+i] = sum_j dM[r][h*c+j] * A[i][j]   for the RC rows of this chunk
-    for (int e = t; e < ATT_RC * c; e += 256) {
-      const int rr = e / c, i = e - rr * c;
-      const int r = r0 + rr;
-      if (r < C) {
-        float s2 = 0.f;
-        for (int j = 0; j < c; ++j) s2 += Dt[rr * c + j] * As[i * ld + j];
-        dwo[(int64_t)r * C + h * c + i] = s2;
+      for (int q = 0; q < CT; ++q) {
+        const int i = ti + 16 * a, j = tj + 16 * q;
+        if (i < c && j < c) acc[a][q] += dAz[(int64_t)rc * c * c + i * c + j];
       }
-    }
   }
-
-  // softmax backward: dS = A * (dA - rowdot),  rowdot_i = sum_j dA_ij A_ij  (16 lanes share one ti)
   float tsum = 0.f;
-  float colsum[8];
+  float colsum[CT];
 #pragma unroll
-  for (int bb = 0; bb < 8; ++bb) colsum[bb] = 0.f;
+  for (int q = 0; q < CT; ++q) colsum[q] = 0.f;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < CT; ++a) {
     const int i = ti + 16 * a;
     float dot = 0.f;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      const int j = tj + 16 * bb;
-      if (i < c && j < c) dot += acc[a][bb] * As[i * ld + j];
-    }
+    for (int q = 0; q < CT; ++q) dot += acc[a][q] * av[a][q];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
     float rqa = 0.f;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      const int j = tj + 16 * bb;
+    for (int q = 0; q < CT; ++q) {
+      const int j = tj + 16 * q;
       float ds = 0.f;
       if (i < c && j < c) {
-        ds = As[i * ld + j] * (acc[a][bb] - dot);
+        ds = av[a][q] * (acc[a][q] - dot);
         const float pv = Pz[i * c + j];
         tsum += ds * pv;
         rqa += ds * pv * temp;
-        colsum[bb] += ds * pv * temp;
+        colsum[q] += ds * pv * temp;
       }
-      acc[a][bb] = ds;
+      acc[a][q] = ds;
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) rqa += __shfl_xor(rqa, o, 64);
     if (tj == 0 && i < c) rqs[i] = rqa;
   }
 #pragma unroll
-  for (int bb = 0; bb < 8; ++bb) {
-    const int j = tj + 16 * bb;
-    if (j < c) colp[ti * c + j] = colsum[bb];
+  for (int q = 0; q < CT; ++q) {
+    const int j = tj + 16 * q;
+    if (j < c) colp[ti * c + j] = colsum[q];
   }
   tsum = wave_sum(tsum);
   if (lane == 0) red[wv] = tsum;
@@ -191,14 +259,14 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
   float* wq = wdq + (int64_t)z * c * 2 * c;
   float* wk = wdk + (int64_t)z * c * 2 * c;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < CT; ++a) {
     const int i = ti + 16 * a;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      const int j = tj + 16 * bb;
+    for (int q = 0; q < CT; ++q) {
+      const int j = tj + 16 * q;
       if (i >= c || j >= c) continue;
       const float nq = nz[i], nk = nz[c + j];
-      const float g1 = temp * acc[a][bb] / (nq * nk);
+      const float g1 = temp * acc[a][q] / (nq * nk);
       wq[i * 2 * c + j] = g1;            // dq_i += g1 * k_j
       wk[j * 2 * c + i] = g1;            // dk_j += g1 * q_i
       // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
@@ -250,33 +318,59 @@ int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtyp
   return launch_reduce_rows(part, out, splits, C, C, accumulate, 1.0f, st);
 }
 
+#define ATTN_CT_SWITCH(ct, CALL)                                       \
+  do {                                                                 \
+    switch (ct) {                                                      \
+      case 1: { constexpr int CT = 1; CALL; } break;                   \
+      case 2: { constexpr int CT = 2; CALL; } break;                   \
+      case 3: { constexpr int CT = 3; CALL; } break;                   \
+      case 4: { constexpr int CT = 4; CALL; } break;                   \
+      case 5: case 6: { constexpr int CT = 6; CALL; } break;           \
+      default: { constexpr int CT = 8; CALL; } break;                  \
+    }                                                                  \
+  } while (0)
+
+size_t attn_bwd_scratch_floats(int B, int C, int heads) {
+  const size_t c = C / heads;
+  return (size_t)B * heads * attn_rchunks(C) * c * c;
+}
+
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
                      float* nrm, float* M, int B, int C, int heads, hipStream_t st) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
-  const size_t lds = (size_t)c * ld * sizeof(float);
-  if (lds > 64 * 1024)
-    MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = ((size_t)c * ld + ATT_RC * c) * sizeof(float);
+  dim3 grid(B * heads, attn_rchunks(C));
   ProfScope ps(st, K_ATTN_FOLD, 4.0 * B * (3.0 * C * c + 2.0 * C * C), 2.0 * B * C * (double)c * C);
-  hipLaunchKernelGGL(attn_fold_kernel, dim3(B * heads), dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, C, heads,
-                     ld);
+  ATTN_CT_SWITCH(attn_ct(c), {
+    if (lds > 64 * 1024)
+      MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fold_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_fold_kernel<CT>), grid, dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, C, heads, ld);
+  });
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
 
+// scratch: attn_bwd_scratch_floats() floats for the per-chunk dA partials
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
-                          const float* wo, float* dwo_part, float* dtemp_part, float* wdq, float* wdk, int B, int C,
-                          int heads, hipStream_t st) {
+                          const float* wo, float* dwo_part, float* dtemp_part, float* wdq, float* wdk, float* scratch,
+                          int B, int C, int heads, hipStream_t st) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
-  const int ld = attn_ld(c);
-  const size_t lds = ((size_t)c * ld + 2 * ATT_RC * c + 16 * c + 2 * c + 4) * sizeof(float);
-  if (lds > 64 * 1024)
-    MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MI_CHECK_ARG(scratch, "mdta: null attention scratch");
+  const int ld = attn_ld(c), rch = attn_rchunks(C);
+  const size_t lds = ((size_t)c * ld + 2 * ATT_RC * c) * sizeof(float);
   ProfScope ps(st, K_ATTN_BWD_SMALL, 4.0 * B * (6.0 * C * c + 3.0 * C * C), 4.0 * B * C * (double)c * C);
-  hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * heads), dim3(256), lds, st, dM, A, P, nrm, temperature, wo, dwo_part,
-                     dtemp_part, wdq, wdk, C, heads, ld);
+  ATTN_CT_SWITCH(attn_ct(c), {
+    if (lds > 64 * 1024)
+      MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_partial_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    hipLaunchKernelGGL((attn_bwd_partial_kernel<CT>), dim3(B * heads, rch), dim3(256), lds, st, dM, A, wo, scratch, dwo_part, C,
+                       heads, ld);
+    hipLaunchKernelGGL((attn_bwd_finish_kernel<CT>), dim3(B * heads), dim3(256), 0, st, (const float*)scratch, rch, A, P, nrm,
+                       temperature, dtemp_part, wdq, wdk, C, heads);
+  });
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -82,7 +82,8 @@ struct MdtaWs {
   // forward
   float* graw; float* ss; void* gram_ws; void* pw_ws; MdtaSaved inf;  // inf: saved-blob stand-in for inference
   // backward
-  float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; void* dqkv; void* dqkv0; void* dw_ws;
+  float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; float* attn_scr; void* dqkv; void* dqkv0;
+  void* dw_ws;
   void* cs_ws;
   size_t bytes;
 };
@@ -97,6 +98,7 @@ static MdtaWs mdta_ws_layout(const mi_mdta_shape* s, void* base) {
   w.dtemp_part = cv.take<float>(fbytes(Z));
   w.wdq = cv.take<float>(fbytes(Z * c * 2 * c));
   w.wdk = cv.take<float>(fbytes(Z * c * 2 * c));
+  w.attn_scr = cv.take<float>(fbytes(attn_bwd_scratch_floats((int)B, (int)C, s->heads)));
   // gram scratch: max over the three contractions this module runs
   mi_gram_desc g1 = mdta_qk_gram(s, (void*)256, (float*)256, (float*)256);
   mi_gram_desc g2 = mdta_dm_gram(s, (void*)256, (void*)256, (float*)256);
@@ -244,8 +246,8 @@ extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   // dM_b = dY V^T
   mi_gram_desc g1 = mdta_dm_gram(s, dout, sv.qkv, w.dM);
   MI_TRY(mi_gram(&g1, w.gram_ws, stream));
-  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, p->temperature, p->proj_w, w.dwo_part, w.dtemp_part, w.wdq, w.wdk, B,
-                               C, hd, st));
+  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, p->temperature, p->proj_w, w.dwo_part, w.dtemp_part, w.wdq, w.wdk,
+                               w.attn_scr, B, C, hd, st));
   MI_TRY(launch_reduce_rows(w.dwo_part, gr->proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
   MI_TRY(launch_reduce_rows(w.dtemp_part, gr->temperature, B, hd, hd, acc, 1.0f, st));
   // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
