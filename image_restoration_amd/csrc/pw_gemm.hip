@@ -8,6 +8,8 @@
 // 16-byte copy (measured: per-tile scalar fp32 staging cost more issue slots than everything else in the kernel).
 // The epilogue stages accumulators through LDS and writes whole 128-byte row segments, 16 bytes per lane.
 // bf16 activations use v_mfma_f32_16x16x32_bf16, fp32 activations the exact v_mfma_f32_16x16x4_f32.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "internal.h"
@@ -27,17 +29,28 @@ __device__ __forceinline__ s16x4 lds_tr_b16(const void* p) {
   return v;
 }
 
-// ---- weight re-pack: fp32 W(m,k) (any strides) -> T image [slice][m_tile][k_chunk][TM][WS_ROW] ----
+template <typename T, int TM> struct PwImg {
+  static constexpr int WS_ROW = PwRow<T>::WS_ROW;
+  static constexpr int W_BYTES = TM * WS_ROW * (int)sizeof(T);
+  static constexpr int W_PAD = (W_BYTES + 4095) / 4096 * 4096;   // chunk image stride: whole KiB per wave for LDS-DMA
+  static constexpr int W_PAD_ELEMS = W_PAD / (int)sizeof(T);
+};
+constexpr int PW_ZERO_BYTES = 256;  // zero block at the head of the workspace: LDS-DMA source for out-of-range rows/cols
+
+// ---- weight re-pack: fp32 W(m,k) (any strides) -> T image [slice][m_tile][k_chunk][chunk stride] of [TM][WS_ROW] ----
 template <typename T>
 __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, int64_t w_bs, int64_t w_gs, int64_t w_sm,
-                                                      int64_t w_sk, T* __restrict__ out, int M, int K, int tm, int k_chunks,
-                                                      int groups_w, int64_t slice_elems, int m_fast) {
+                                                      int64_t w_sk, unsigned char* __restrict__ ws, int M, int K, int tm,
+                                                      int k_chunks, int groups_w, int64_t slice_elems, int chunk_elems,
+                                                      int m_fast) {
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < PW_ZERO_BYTES / 4) reinterpret_cast<float*>(ws)[threadIdx.x] = 0.f;
+  T* out = reinterpret_cast<T*>(ws + PW_ZERO_BYTES);
   const int slice = blockIdx.y;
   const int sb = slice / groups_w, sg = slice - sb * groups_w;
   const float* wz = w + sb * w_bs + sg * w_gs;
   T* oz = out + (int64_t)slice * slice_elems;
-  const int m_tiles = (int)(slice_elems / ((int64_t)k_chunks * tm * WS_ROW));
+  const int m_tiles = (int)(slice_elems / ((int64_t)k_chunks * chunk_elems));
   const int64_t total = (int64_t)m_tiles * k_chunks * tm * PW_KC;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     // m_fast: consecutive threads walk m (coalesced for W^T callers), else k
@@ -48,156 +61,92 @@ __global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ 
     const int kc = (int)(r % k_chunks), mt = (int)(r / k_chunks);
     const int m = mt * tm + mm, k = kc * PW_KC + kk;
     const float v = (m < M && k < K) ? wz[(int64_t)m * w_sm + (int64_t)k * w_sk] : 0.f;
-    oz[(((int64_t)mt * k_chunks + kc) * tm + mm) * WS_ROW + kk] = Cvt<T>::from(v);
+    oz[((int64_t)mt * k_chunks + kc) * chunk_elems + mm * WS_ROW + kk] = Cvt<T>::from(v);
   }
 }
 
 struct PwG {
   PwK k;
-  const void* wp;        // packed weights
-  int64_t wp_slice;      // elements per packed slice
+  const unsigned char* ws;  // [zero block][packed weights]
+  int64_t wp_slice;         // elements per packed slice
   int wp_per_batch, wp_per_group, k_chunks;
 };
 
-template <typename T, int MF>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
-  const PwK& p = q.k;
+// X chunk addressing in LDS.  Register-staged image: [32][PW_XS] padded rows.  LDS-DMA image: [32][64] unpadded rows
+// (a wave's 1 KiB DMA piece = whole rows) with the 16-byte pieces of row r XOR-permuted by ((r>>1)&3)<<1 so that the
+// bf16 transposed reads stay bank-conflict free (the same permutation is applied to the DMA source address).
+template <typename T, bool DMA> struct PwXAddr {
+  static __device__ __forceinline__ int at(int r, int n) {
+    if (!DMA) return r * PW_XS + n;
+    if (sizeof(T) == 4) return r * PW_TN + n;
+    return r * PW_TN + ((((n >> 3) ^ (((r >> 1) & 3) << 1))) << 3) + (n & 7);
+  }
+};
+
+// one 32-deep chunk of MFMAs: acc[nf][mf] += X^T(pixels 16nf.., k) * W^T(k, channels mw+16mf..)
+template <typename T, int MF, bool DMA>
+__device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*acc)[MF], int mw, int li, int g) {
   constexpr bool F32 = std::is_same<T, float>::value;
-  constexpr int TM = 64 * MF;
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
-  constexpr int X_ELEMS = PW_KC * PW_XS, W_ELEMS = TM * WS_ROW;
-  constexpr int STAGE_BYTES = (X_ELEMS + W_ELEMS) * (int)sizeof(T);
-  constexpr int SLAB_BYTES = 4 * 16 * (PW_TN + 4) * (int)sizeof(float);  // epilogue: 4 waves x 16 rows x fp32
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES > SLAB_BYTES ? STAGE_BYTES : SLAB_BYTES];
-  T* const Xs = reinterpret_cast<T*>(lds_raw);
-  T* const Ws = Xs + X_ELEMS;
-
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
-  const int64_t n0 = (int64_t)blockIdx.x * PW_TN;
-  const int m0 = blockIdx.y * TM;
-  const int ktot = p.k1 + p.k2;
-  const int nchunks = q.k_chunks;
-
-  const T* x1 = (const T*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
-  const T* x2 = p.x2 ? (const T*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : nullptr;
-  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
-  const u32x4* wpk = reinterpret_cast<const u32x4*>((const T*)q.wp + (int64_t)wslice * q.wp_slice +
-                                                    (int64_t)blockIdx.y * nchunks * W_ELEMS);
-
-  // ---- staging registers ----
-  constexpr int XV = F32 ? 2 : 1;                             // 16-byte vectors per thread for its 8 X elements
-  constexpr int W_VECS = W_ELEMS * (int)sizeof(T) / 16;       // 16-byte vectors per weight chunk image
-  constexpr int WV = (W_VECS + 255) / 256;
-  u32x4 xreg[XV], wreg[WV];
-  const int xr_row = t >> 3, xr_col = (t & 7) * 8;
-
-  auto load_stage = [&](int chunk) {
-    const int k = chunk * PW_KC + xr_row;
-    const T* row = nullptr;
-    if (k < p.k1) row = x1 + (int64_t)k * p.n;
-    else if (k < ktot) row = x2 + (int64_t)(k - p.k1) * p.n;
-    const int64_t n = n0 + xr_col;
-    constexpr int EPVX = 8 / XV;  // elements per 16-byte vector
+  using XA = PwXAddr<T, DMA>;
+  if constexpr (F32) {
 #pragma unroll
-    for (int v = 0; v < XV; ++v) {
-      const int64_t nn = n + v * EPVX;
-      if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPVX == 0 for every row, so the vector is all-in or all-out
-        xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
-      } else {
-        __attribute__((aligned(16))) T tmp[EPVX];
+    for (int ks = 0; ks < PW_KC / 4; ++ks) {
+      const int kk = 4 * ks + g;
+      float a[4], b[MF];
 #pragma unroll
-        for (int j = 0; j < EPVX; ++j) tmp[j] = (row && nn + j < p.n) ? row[nn + j] : Cvt<T>::from(0.f);
-        xreg[v] = *reinterpret_cast<u32x4*>(tmp);
-      }
-    }
-    const u32x4* wc = wpk + (int64_t)chunk * W_VECS;
+      for (int nf = 0; nf < 4; ++nf) a[nf] = Xs[XA::at(kk, 16 * nf + li)];
 #pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int vid = t + 256 * i;
-      if (vid < W_VECS) wreg[i] = wc[vid];
-    }
-  };
-  auto write_stage = [&]() {
-#pragma unroll
-    for (int v = 0; v < XV; ++v)
-      *reinterpret_cast<u32x4*>(&Xs[xr_row * PW_XS + xr_col + v * (8 / XV)]) = xreg[v];
-    u32x4* wd = reinterpret_cast<u32x4*>(Ws);
-#pragma unroll
-    for (int i = 0; i < WV; ++i) {
-      const int vid = t + 256 * i;
-      if (vid < W_VECS) wd[vid] = wreg[i];
-    }
-  };
-
-  f32x4 acc[4][MF];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int mw = wv * MF * 16;  // this wave's first m inside the tile
-
-  load_stage(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();
-    write_stage();
-    __syncthreads();
-    if (c + 1 < nchunks) load_stage(c + 1);
-    if constexpr (F32) {
-#pragma unroll
-      for (int ks = 0; ks < PW_KC / 4; ++ks) {
-        const int kk = 4 * ks + g;
-        float a[4], b[MF];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) a[nf] = Xs[kk * PW_XS + 16 * nf + li];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) b[mf] = Ws[(mw + 16 * mf + li) * WS_ROW + kk];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf)
-            acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
-      }
-    } else {
-      // k slots: element j<4 of lane group g is k = 4g+j, element j>=4 is k = 16+4g+(j-4), for A and B alike.
-      // The tr-reads are inline asm, so their results are tied through the s_waitcnt statement below:
-      // every consumer is data-dependent on the wait and cannot be scheduled ahead of it.
-      const int qq = li >> 2, pp = li & 3;
-      s16x4 alo[4], ahi[4], blo[MF], bhi[MF];
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        alo[nf] = lds_tr_b16(&Xs[(4 * g + qq) * PW_XS + 16 * nf + 4 * pp]);
-        ahi[nf] = lds_tr_b16(&Xs[(16 + 4 * g + qq) * PW_XS + 16 * nf + 4 * pp]);
-      }
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const T* wr = &Ws[(mw + 16 * mf + li) * WS_ROW + 4 * g];
-        blo[mf] = *reinterpret_cast<const s16x4*>(wr);
-        bhi[mf] = *reinterpret_cast<const s16x4*>(wr + 16);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
-                     "+v"(ahi[3])
-                   :
-                   : "memory");
-      s16x8 a[4], b[MF];
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) a[nf] = __builtin_shufflevector(alo[nf], ahi[nf], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) b[mf] = __builtin_shufflevector(blo[mf], bhi[mf], 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int mf = 0; mf < MF; ++mf) b[mf] = Ws[(mw + 16 * mf + li) * WS_ROW + kk];
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
     }
+  } else {
+    // k slots: element j<4 of lane group g is k = 4g+j, element j>=4 is k = 16+4g+(j-4), for A and B alike.
+    // The tr-reads are inline asm, so their results are tied through the s_waitcnt statement below:
+    // every consumer is data-dependent on the wait and cannot be scheduled ahead of it.
+    const int qq = li >> 2, pp = li & 3;
+    s16x4 alo[4], ahi[4], blo[MF], bhi[MF];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      alo[nf] = lds_tr_b16(&Xs[XA::at(4 * g + qq, 16 * nf + 4 * pp)]);
+      ahi[nf] = lds_tr_b16(&Xs[XA::at(16 + 4 * g + qq, 16 * nf + 4 * pp)]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const T* wr = &Ws[(mw + 16 * mf + li) * WS_ROW + 4 * g];
+      blo[mf] = *reinterpret_cast<const s16x4*>(wr);
+      bhi[mf] = *reinterpret_cast<const s16x4*>(wr + 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
+                   "+v"(ahi[3])
+                 :
+                 : "memory");
+    s16x8 a[4], b[MF];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) a[nf] = __builtin_shufflevector(alo[nf], ahi[nf], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) b[mf] = __builtin_shufflevector(blo[mf], bhi[mf], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
   }
+}
 
-  // ---- epilogue: lane holds pixels n0+16nf+4g+{0..3} of output channel m0+mw+16mf+li.  Stored from the
-  // accumulator that is 8 bytes per lane scattered over 16 rows; the rows are therefore staged through LDS (one
-  // 16-row slab per wave at a time) and written as whole 128-byte row segments, 16 bytes per lane.
+// Epilogue: lane holds pixels n0+16nf+4g+{0..3} of output channel m0+mw+16mf+li — 8 bytes per lane scattered over
+// 16 rows.  The rows are staged through LDS (one 16-row fp32 slab per wave at a time, so the only rounding is the final
+// store) and written as whole 128-byte row segments, 16 bytes per lane, with bias and residual added on the way.
+template <typename T, int MF>
+__device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const f32x4 (*acc)[MF], int zb, int zg, int m0,
+                                            int64_t n0, int mw, int lane, int wv) {
+  constexpr bool F32 = std::is_same<T, float>::value;
+  const int li = lane & 15, g = lane >> 4;
   T* yz = (T*)p.y + zb * p.y_bs + zg * p.y_gs;
   const T* rz = p.r ? (const T*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
   const float* bz = p.bias ? p.bias + zg * p.bias_gs : nullptr;
@@ -205,7 +154,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
   constexpr int OS = PW_TN + 4;           // fp32 slab row stride (floats): 272 bytes
   constexpr int LPR = PW_TN / EPV;        // lanes per row on the way out
   constexpr int RPI = 64 / LPR;           // rows per store instruction
-  float* slab = reinterpret_cast<float*>(lds_raw) + wv * 16 * OS;  // kept in fp32: the only rounding is the final store
+  float* slab = lds_f32 + wv * 16 * OS;
   __syncthreads();                        // every wave is done reading the last chunk
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
@@ -247,49 +196,244 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
   }
 }
 
-struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group; int64_t slice_elems; size_t bytes; };
+constexpr int PW_SLAB_BYTES = 4 * 16 * (PW_TN + 4) * (int)sizeof(float);  // epilogue: 4 waves x 16 rows x fp32
+
+// ---- register-staged form: any alignment / ragged pixel counts; one chunk of prefetch ----
+template <typename T, int MF>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
+  const PwK& p = q.k;
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int TM = 64 * MF;
+  using IM = PwImg<T, TM>;
+  constexpr int X_ELEMS = PW_KC * PW_XS, W_ELEMS = TM * IM::WS_ROW;
+  constexpr int STAGE_BYTES = (X_ELEMS + W_ELEMS) * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES > PW_SLAB_BYTES ? STAGE_BYTES : PW_SLAB_BYTES];
+  T* const Xs = reinterpret_cast<T*>(lds_raw);
+  T* const Ws = Xs + X_ELEMS;
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int64_t n0 = (int64_t)blockIdx.x * PW_TN;
+  const int m0 = blockIdx.y * TM;
+  const int ktot = p.k1 + p.k2;
+  const int nchunks = q.k_chunks;
+
+  const T* x1 = (const T*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  const T* x2 = p.x2 ? (const T*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : nullptr;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  const T* wpk = reinterpret_cast<const T*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
+                 (int64_t)blockIdx.y * nchunks * IM::W_PAD_ELEMS;
+
+  constexpr int XV = F32 ? 2 : 1;                             // 16-byte vectors per thread for its 8 X elements
+  constexpr int W_VECS = IM::W_BYTES / 16;                    // 16-byte vectors per weight chunk image
+  constexpr int WV = (W_VECS + 255) / 256;
+  u32x4 xreg[XV], wreg[WV];
+  const int xr_row = t >> 3, xr_col = (t & 7) * 8;
+
+  auto load_stage = [&](int chunk) {
+    const int k = chunk * PW_KC + xr_row;
+    const T* row = nullptr;
+    if (k < p.k1) row = x1 + (int64_t)k * p.n;
+    else if (k < ktot) row = x2 + (int64_t)(k - p.k1) * p.n;
+    const int64_t n = n0 + xr_col;
+    constexpr int EPVX = 8 / XV;  // elements per 16-byte vector
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int64_t nn = n + v * EPVX;
+      if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPVX == 0 for every row, so the vector is all-in or all-out
+        xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
+      } else {
+        __attribute__((aligned(16))) T tmp[EPVX];
+#pragma unroll
+        for (int j = 0; j < EPVX; ++j) tmp[j] = (row && nn + j < p.n) ? row[nn + j] : Cvt<T>::from(0.f);
+        xreg[v] = *reinterpret_cast<u32x4*>(tmp);
+      }
+    }
+    const u32x4* wc = reinterpret_cast<const u32x4*>(wpk + (int64_t)chunk * IM::W_PAD_ELEMS);
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wreg[i] = wc[vid];
+    }
+  };
+  auto write_stage = [&]() {
+#pragma unroll
+    for (int v = 0; v < XV; ++v)
+      *reinterpret_cast<u32x4*>(&Xs[xr_row * PW_XS + xr_col + v * (8 / XV)]) = xreg[v];
+    u32x4* wd = reinterpret_cast<u32x4*>(Ws);
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wd[vid] = wreg[i];
+    }
+  };
+
+  f32x4 acc[4][MF];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int mw = wv * MF * 16;  // this wave's first m inside the tile
+
+  load_stage(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    write_stage();
+    __syncthreads();
+    if (c + 1 < nchunks) load_stage(c + 1);
+    pw_chunk_mma<T, MF, false>(Xs, Ws, acc, mw, li, g);
+  }
+  pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_raw), acc, zb, zg, m0, n0, mw, lane, wv);
+}
+
+// ---- LDS-DMA form (16-byte aligned rows): global_load_lds_dwordx4 straight into a 3-deep ring of chunk images, two
+// chunks in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier per chunk; no staging registers, no ds_write.
+template <typename T, int MF>
+__global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwG q) {
+  const PwK& p = q.k;
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int TM = 64 * MF;
+  using IM = PwImg<T, TM>;
+  constexpr int X_BYTES = PW_KC * PW_TN * (int)sizeof(T);      // 4 KiB (bf16) / 8 KiB (fp32): whole KiB per wave
+  constexpr int NX = X_BYTES / 4096;                           // X DMA instructions per wave per chunk
+  constexpr int NW = IM::W_PAD / 4096;                         // W DMA instructions per wave per chunk
+  constexpr int NI = NX + NW;
+  constexpr int BUF_BYTES = X_BYTES + IM::W_PAD;
+  constexpr int NBUF = 3;
+  static_assert(NBUF * BUF_BYTES >= PW_SLAB_BYTES, "ring must cover the epilogue slabs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int64_t n0 = (int64_t)blockIdx.x * PW_TN;
+  const int m0 = blockIdx.y * TM;
+  const int ktot = p.k1 + p.k2;
+  const int nchunks = q.k_chunks;
+
+  const T* x1 = (const T*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  const T* x2 = p.x2 ? (const T*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : nullptr;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  const unsigned char* wpk = q.ws + PW_ZERO_BYTES +
+                             ((int64_t)wslice * q.wp_slice + (int64_t)blockIdx.y * nchunks * IM::W_PAD_ELEMS) * sizeof(T);
+  const unsigned char* zero_src = q.ws;  // 256 zero bytes
+
+  // X piece geometry of this lane: rows of (64 * sizeof(T)) bytes, ROWS_PI rows per 1 KiB piece
+  constexpr int ROW_BYTES = PW_TN * (int)sizeof(T);
+  constexpr int ROWS_PI = 1024 / ROW_BYTES;        // 8 (bf16) / 4 (fp32)
+  constexpr int PCS = ROW_BYTES / 16;              // 16-byte pieces per row: 8 / 16
+  const int xrow_in_piece = lane / PCS, xpc = lane % PCS;
+
+  auto issue = [&](int chunk) {
+    unsigned char* buf = lds_dyn + (chunk % NBUF) * BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int piece = wv * NX + j;                         // 1 KiB piece index inside the X image
+      const int r = piece * ROWS_PI + xrow_in_piece;         // row of the chunk (0..31)
+      const int k = chunk * PW_KC + r;
+      const int src_pc = F32 ? xpc : (xpc ^ (((r >> 1) & 3) << 1));  // source-side swizzle (bf16)
+      const int64_t n = n0 + (int64_t)src_pc * (16 / (int)sizeof(T));
+      const unsigned char* src = zero_src + (lane & 15) * 16;
+      if (n < p.n) {
+        if (k < p.k1) src = reinterpret_cast<const unsigned char*>(x1 + (int64_t)k * p.n + n);
+        else if (k < ktot) src = reinterpret_cast<const unsigned char*>(x2 + (int64_t)(k - p.k1) * p.n + n);
+      }
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int piece = wv * NW + j;
+      const unsigned char* src = wpk + (int64_t)chunk * IM::W_PAD + piece * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + X_BYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][MF];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int mw = wv * MF * 16;
+
+  issue(0);
+  if (nchunks > 1) issue(1);
+  for (int c = 0; c < nchunks; ++c) {
+    // this wave's pieces of chunk c have landed once at most the NI pieces of chunk c+1 are still outstanding
+    if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's pieces of chunk c are in; everyone is done reading buffer (c-1)%3
+    if (c + 2 < nchunks) issue(c + 2);
+    const T* Xs = reinterpret_cast<const T*>(lds_dyn + (c % NBUF) * BUF_BYTES);
+    const T* Ws = reinterpret_cast<const T*>(lds_dyn + (c % NBUF) * BUF_BYTES + X_BYTES);
+    pw_chunk_mma<T, MF, true>(Xs, Ws, acc, mw, li, g);
+  }
+  pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_dyn), acc, zb, zg, m0, n0, mw, lane, wv);
+}
+
+struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group, chunk_elems; int64_t slice_elems; size_t bytes; };
 
 static PwPlan pw_plan(const mi_pw_desc* d) {
   PwPlan pl;
-  // largest m-tile whose padding stays within 25% of the 64-granular minimum
+  // m-tile 128 when its padding stays within 25% of the 64-granular minimum, else 64.  (256-row tiles measured 5-8%
+  // slower on the wide GDFN shapes: fewer resident workgroups; profiles/r01_n_pw_tile_staging_ab.log)
   const int mmin = cdiv(d->m, 64) * 64;
-  pl.tm = 64;
-  if (cdiv(d->m, 256) * 256 * 4 <= mmin * 5) pl.tm = 256;
-  else if (cdiv(d->m, 128) * 128 * 4 <= mmin * 5) pl.tm = 128;
+  pl.tm = (cdiv(d->m, 128) * 128 * 4 <= mmin * 5) ? 128 : 64;
   pl.m_tiles = cdiv(d->m, pl.tm);
   pl.k_chunks = cdiv(d->k1 + d->k2, PW_KC);
   pl.per_batch = d->w_bs != 0;
   pl.per_group = d->w_gs != 0;
   pl.slices = (pl.per_batch ? d->batch : 1) * (pl.per_group ? d->groups : 1);
   const int ws_row = d->dtype == MI_F32 ? PwRow<float>::WS_ROW : PwRow<bf16>::WS_ROW;
-  pl.slice_elems = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * ws_row;
-  pl.bytes = align_up((size_t)pl.slices * pl.slice_elems * dtype_size(d->dtype), 256);
+  const size_t es = dtype_size(d->dtype);
+  pl.chunk_elems = (int)(align_up((size_t)pl.tm * ws_row * es, 4096) / es);
+  pl.slice_elems = (int64_t)pl.m_tiles * pl.k_chunks * pl.chunk_elems;
+  pl.bytes = align_up(PW_ZERO_BYTES + (size_t)pl.slices * pl.slice_elems * es, 256);
   return pl;
+}
+
+template <typename T, int MF>
+static int pw_launch_dma(const PwG& q, dim3 grid, hipStream_t st) {
+  using IM = PwImg<T, 64 * MF>;
+  constexpr int lds = 3 * (PW_KC * PW_TN * (int)sizeof(T) + IM::W_PAD);
+  if (lds > 64 * 1024)
+    MI_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((pw_gemm_dma_kernel<T, MF>), grid, dim3(256), lds, st, q);
+  return MI_OK;
 }
 
 template <typename T>
 static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* ws, hipStream_t st) {
-  {  // re-pack the weights of every slice
-    const int64_t total = pl.slice_elems / PwRow<T>::WS_ROW * PW_KC;
+  {  // re-pack the weights of every slice (and refresh the zero block)
+    const int64_t total = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * PW_KC;
     int gx = cdiv(total, 256);
     if (gx > 1024) gx = 1024;
     ProfScope ps(st, K_PW_PACK, 4.0 * d->m * (d->k1 + d->k2) * pl.slices + (double)pl.bytes, 0.0);
     hipLaunchKernelGGL((pw_pack_kernel<T>), dim3(gx, pl.slices), dim3(256), 0, st, d->w, d->w_bs, d->w_gs, d->w_sm, d->w_sk,
-                       (T*)ws, d->m, d->k1 + d->k2, pl.tm, pl.k_chunks, pl.per_group ? d->groups : 1, pl.slice_elems,
-                       d->w_sk != 1 ? 1 : 0);
+                       (unsigned char*)ws, d->m, d->k1 + d->k2, pl.tm, pl.k_chunks, pl.per_group ? d->groups : 1,
+                       pl.slice_elems, pl.chunk_elems, d->w_sk != 1 ? 1 : 0);
     MI_LAUNCH_CHECK();
   }
   PwG q;
-  q.k = k; q.wp = ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch; q.wp_per_group = pl.per_group;
-  q.k_chunks = pl.k_chunks;
+  q.k = k; q.ws = (const unsigned char*)ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch;
+  q.wp_per_group = pl.per_group; q.k_chunks = pl.k_chunks;
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
   const double Z = (double)d->batch * k.groups, kt = k.k1 + k.k2;
   ProfScope ps(st, K_PW_GEMM, (kt + k.m + (k.r ? k.m : 0)) * (double)k.n * Z * sizeof(T) + 4.0 * k.m * kt,
                2.0 * k.m * kt * (double)k.n * Z);
-  if (pl.tm == 256) hipLaunchKernelGGL((pw_gemm_kernel<T, 4>), grid, block, 0, st, q);
-  else if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, q);
-  else hipLaunchKernelGGL((pw_gemm_kernel<T, 1>), grid, block, 0, st, q);
+  // The LDS-DMA ring measured 5-12% SLOWER than register staging on every Restormer shape (K is 2-16 chunks, so the
+  // per-tile prologue and epilogue dominate and its 3 x chunk LDS footprint halves the resident workgroups).  It stays
+  // opt-in (MI_PW_DMA=1) as the base of a persistent cross-tile pipeline; tests run it through the same parity cases.
+  const bool dma = getenv("MI_PW_DMA") != nullptr;
+  if (k.vec_ok && dma) {
+    if (pl.tm == 128) MI_TRY((pw_launch_dma<T, 2>(q, grid, st)));
+    else MI_TRY((pw_launch_dma<T, 1>(q, grid, st)));
+  } else {
+    if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((pw_gemm_kernel<T, 1>), grid, block, 0, st, q);
+  }
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

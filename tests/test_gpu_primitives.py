@@ -250,9 +250,15 @@ def _pw_raw(x1, x2, w, bias, res, M, groups, w_per_image, transposed):
     (96, 510, 0, 1, False, (8, 64)), (510, 96, 0, 1, False, (8, 64)), (48, 48, 48, 2, True, (16, 64)),
     (96, 96, 96, 1, True, (8, 72)), (37, 20, 13, 3, True, (5, 7)), (48, 48, 0, 1, True, (9, 11))])
 @pytest.mark.parametrize("dtype", DT)
-def test_pw_full_descriptor_exact_on_integers(dtype, transposed, M, K1, K2, groups, per_image, hw):
+@pytest.mark.parametrize("dma", [False, True])
+def test_pw_full_descriptor_exact_on_integers(monkeypatch, dma, dtype, transposed, M, K1, K2, groups, per_image, hw):
     """The full mi_pw_desc surface: K 48..510, both weight orientations, two K-panels, head groups, per-image weights,
-    ragged pixel counts.  Integer data: exact up to the final rounding of the store."""
+    ragged pixel counts; register-staged kernel and (dma=True, aligned shapes) the opt-in LDS-DMA ring kernel.
+    Integer data: exact up to the final rounding of the store."""
+    if dma:
+        monkeypatch.setenv("MI_PW_DMA", "1")
+    else:
+        monkeypatch.delenv("MI_PW_DMA", raising=False)
     B = 2
     K = K1 + K2
     x1 = ints((B, groups * K1, *hw), 91).to(dtype)
