@@ -50,6 +50,21 @@ class MdtaGrads(C.Structure):
                 ("proj_w", fp), ("proj_b", fp), ("accumulate", C.c_int)]
 
 
+class XmdtaShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("heads", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("dtype", C.c_int), ("ks_q", C.c_int), ("ks_kv", C.c_int)]
+
+
+class XmdtaParams(C.Structure):
+    _fields_ = [(n, fp) for n in ("temperature", "q_w", "q_b", "q_dw_w", "q_dw_b", "kv_w", "kv_b", "kv_dw_w", "kv_dw_b",
+                                  "proj_w", "proj_b")]
+
+
+class XmdtaGrads(C.Structure):
+    _fields_ = [(n, fp) for n in ("temperature", "q_w", "q_b", "q_dw_w", "q_dw_b", "kv_w", "kv_b", "kv_dw_w", "kv_dw_b",
+                                  "proj_w", "proj_b")] + [("accumulate", C.c_int)]
+
+
 class GdfnShape(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("dtype", C.c_int), ("ks", C.c_int)]
@@ -88,6 +103,11 @@ SIGNATURES = {
     "mi_mdta_fwd": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), vp, vp, vp, vp, vp, vp]),
     "mi_mdta_bwd": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), vp, vp, vp, C.POINTER(MdtaGrads), vp, vp,
                               vp]),
+    "mi_xmdta_saved_bytes": (C.c_size_t, [C.POINTER(XmdtaShape)]),
+    "mi_xmdta_workspace": (C.c_size_t, [C.POINTER(XmdtaShape)]),
+    "mi_xmdta_fwd": (C.c_int, [C.POINTER(XmdtaShape), C.POINTER(XmdtaParams), vp, vp, vp, vp, vp, vp, vp]),
+    "mi_xmdta_bwd": (C.c_int, [C.POINTER(XmdtaShape), C.POINTER(XmdtaParams), vp, vp, vp, vp, vp, C.POINTER(XmdtaGrads), vp,
+                               vp, vp]),
     "mi_gdfn_saved_bytes": (C.c_size_t, [C.POINTER(GdfnShape)]),
     "mi_gdfn_workspace": (C.c_size_t, [C.POINTER(GdfnShape)]),
     "mi_gdfn_fwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, vp, vp, vp]),
@@ -95,6 +115,8 @@ SIGNATURES = {
                               vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, fp, vp]),
+    "mi_gap_fwd": (C.c_int, [vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_gap_bwd": (C.c_int, [fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),
     "mi_l1_loss": (C.c_int, [vp, vp, vp, fp, c_i64, C.c_float, C.c_int, vp]),
     "mi_prof_enable": (C.c_int, [C.c_int]),

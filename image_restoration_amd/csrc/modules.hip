@@ -25,46 +25,42 @@ static mi_pw_desc conv1x1(const void* x, int K, const float* w, bool transposed,
   return d;
 }
 
-// ------------------------------------------------------------------ MDTA
-struct MdtaSaved {
-  void* qkv0; void* qkv; float* A; float* P; float* nrm; float* M; size_t bytes;
+// ------------------------------------------------------------------ attention core (shared by MDTA and cross-MDTA)
+// q, k, v are channel slices of NCHW tensors: base pointer + batch stride (elements); heads are contiguous channel
+// groups of c = C/heads rows (Restormer.py:117-119 'b (head c) h w').
+struct QkvView { const void* q; int64_t q_bs; const void* k; int64_t k_bs; const void* v; int64_t v_bs; };
+struct AttnDims { int B, C, heads, dtype; int64_t N; };
+struct AttnSaved { float* A; float* P; float* nrm; float* M; };
+struct AttnScratch {
+  float* graw; float* ss; float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; float* attn_scr;
+  void* gram_ws; void* pw_ws; void* cs_ws;
 };
-static MdtaSaved mdta_saved_layout(const mi_mdta_shape* s, void* base) {
-  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B, c = C / s->heads, Z = B * s->heads;
-  Carver cv(base);
-  MdtaSaved r;
-  r.qkv0 = cv.take(tbytes(B * 3 * C * N, s->dtype));
-  r.qkv = cv.take(tbytes(B * 3 * C * N, s->dtype));
-  r.A = cv.take<float>(fbytes(Z * c * c));
-  r.P = cv.take<float>(fbytes(Z * c * c));
-  r.nrm = cv.take<float>(fbytes(Z * 2 * c));
-  r.M = cv.take<float>(fbytes(B * C * C));
-  r.bytes = cv.off;
-  return r;
+
+static void attn_saved_carve(Carver& cv, const AttnDims& d, AttnSaved* r) {
+  const size_t C = d.C, B = d.B, c = C / d.heads, Z = B * d.heads;
+  r->A = cv.take<float>(fbytes(Z * c * c));
+  r->P = cv.take<float>(fbytes(Z * c * c));
+  r->nrm = cv.take<float>(fbytes(Z * 2 * c));
+  r->M = cv.take<float>(fbytes(B * C * C));
 }
 
-static mi_gram_desc mdta_qk_gram(const mi_mdta_shape* s, const void* qkv, float* graw, float* ss) {
-  const int64_t N = (int64_t)s->H * s->W;
-  const int C = s->C, c = C / s->heads;
-  const size_t es = dtype_size(s->dtype);
+static mi_gram_desc attn_qk_gram(const AttnDims& d, const QkvView& v, float* graw, float* ss) {
+  const int c = d.C / d.heads;
   mi_gram_desc g;
   memset(&g, 0, sizeof(g));
-  g.a = qkv; g.a_bs = 3 * (int64_t)C * N; g.a_gs = (int64_t)c * N; g.ma = c;
-  g.b = (const char*)qkv + (size_t)C * N * es; g.b_bs = g.a_bs; g.b_gs = g.a_gs; g.mb = c;
-  g.n = N; g.batch = s->B; g.groups = s->heads; g.dtype = s->dtype;
-  g.sum_batch = 0; g.accumulate = 0; g.out = graw; g.out_ld = c; g.out_zs = (int64_t)c * c; g.sumsq = ss;
+  g.a = v.q; g.a_bs = v.q_bs; g.a_gs = (int64_t)c * d.N; g.ma = c;
+  g.b = v.k; g.b_bs = v.k_bs; g.b_gs = (int64_t)c * d.N; g.mb = c;
+  g.n = d.N; g.batch = d.B; g.groups = d.heads; g.dtype = d.dtype;
+  g.out = graw; g.out_ld = c; g.out_zs = (int64_t)c * c; g.sumsq = ss;
   return g;
 }
-static mi_gram_desc mdta_dm_gram(const mi_mdta_shape* s, const void* dout, const void* qkv, float* dM) {
-  const int64_t N = (int64_t)s->H * s->W;
-  const int C = s->C;
-  const size_t es = dtype_size(s->dtype);
+static mi_gram_desc attn_dm_gram(const AttnDims& d, const void* dout, const QkvView& v, float* dM) {
   mi_gram_desc g;
   memset(&g, 0, sizeof(g));
-  g.a = dout; g.a_bs = (int64_t)C * N; g.ma = C;
-  g.b = (const char*)qkv + (size_t)2 * C * N * es; g.b_bs = 3 * (int64_t)C * N; g.mb = C;
-  g.n = N; g.batch = s->B; g.groups = 1; g.dtype = s->dtype;
-  g.out = dM; g.out_ld = C; g.out_zs = (int64_t)C * C;
+  g.a = dout; g.a_bs = (int64_t)d.C * d.N; g.ma = d.C;
+  g.b = v.v; g.b_bs = v.v_bs; g.mb = d.C;
+  g.n = d.N; g.batch = d.B; g.groups = 1; g.dtype = d.dtype;
+  g.out = dM; g.out_ld = d.C; g.out_zs = (int64_t)d.C * d.C;
   return g;
 }
 static mi_gram_desc wgrad_gram(const void* dy, int m, const void* x, int k, int B, int64_t N, int dtype, float* out,
@@ -77,48 +73,126 @@ static mi_gram_desc wgrad_gram(const void* dy, int m, const void* x, int k, int 
   g.sum_batch = 1; g.accumulate = accumulate; g.out = out; g.out_ld = k; g.out_zs = 0;
   return g;
 }
+// the grouped per-image GEMM of the q/k gradients (two K-panels of c rows each, weights [Z][c][2c])
+static mi_pw_desc attn_dqk_desc(const AttnDims& d, const void* xa, int64_t xa_bs, const void* xb, int64_t xb_bs,
+                                const float* w, void* y, int64_t y_bs) {
+  const int c = d.C / d.heads;
+  mi_pw_desc dd;
+  memset(&dd, 0, sizeof(dd));
+  dd.x1 = xa; dd.x1_bs = xa_bs; dd.x1_gs = (int64_t)c * d.N; dd.k1 = c;
+  dd.x2 = xb; dd.x2_bs = xb_bs; dd.x2_gs = (int64_t)c * d.N; dd.k2 = c;
+  dd.w = w; dd.w_bs = (int64_t)d.heads * c * 2 * c; dd.w_gs = (int64_t)c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
+  dd.y = y; dd.y_bs = y_bs; dd.y_gs = (int64_t)c * d.N;
+  dd.m = c; dd.n = d.N; dd.batch = d.B; dd.groups = d.heads; dd.dtype = d.dtype;
+  return dd;
+}
 
-struct MdtaWs {
-  // forward
-  float* graw; float* ss; void* gram_ws; void* pw_ws; MdtaSaved inf;  // inf: saved-blob stand-in for inference
-  // backward
-  float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; float* attn_scr; void* dqkv; void* dqkv0;
-  void* dw_ws;
-  void* cs_ws;
-  size_t bytes;
-};
+static void attn_scratch_carve(Carver& cv, const AttnDims& d, AttnScratch* w) {
+  const size_t C = d.C, B = d.B, c = C / d.heads, Z = B * d.heads;
+  w->graw = cv.take<float>(fbytes(Z * c * c));
+  w->ss = cv.take<float>(fbytes(Z * 2 * c));
+  w->dM = cv.take<float>(fbytes(B * C * C));
+  w->dwo_part = cv.take<float>(fbytes(B * C * C));
+  w->dtemp_part = cv.take<float>(fbytes(Z));
+  w->wdq = cv.take<float>(fbytes(Z * c * 2 * c));
+  w->wdk = cv.take<float>(fbytes(Z * c * 2 * c));
+  w->attn_scr = cv.take<float>(fbytes(attn_bwd_scratch_floats((int)B, (int)C, d.heads)));
+  QkvView fake{(void*)256, 0, (void*)256, 0, (void*)256, 0};
+  mi_gram_desc g1 = attn_qk_gram(d, fake, (float*)256, (float*)256);
+  mi_gram_desc g2 = attn_dm_gram(d, (void*)256, fake, (float*)256);
+  w->gram_ws = nullptr; w->pw_ws = nullptr; w->cs_ws = nullptr;  // sized by the caller together with its own GEMMs
+  (void)g1; (void)g2;
+}
+static size_t attn_gram_ws_bytes(const AttnDims& d) {
+  QkvView fake{(void*)256, 0, (void*)256, 0, (void*)256, 0};
+  mi_gram_desc g1 = attn_qk_gram(d, fake, (float*)256, (float*)256);
+  mi_gram_desc g2 = attn_dm_gram(d, (void*)256, fake, (float*)256);
+  return max2(mi_gram_workspace(&g1), mi_gram_workspace(&g2));
+}
+static size_t attn_pw_ws_bytes(const AttnDims& d) {
+  mi_pw_desc b = conv1x1((void*)256, d.C, (const float*)256, false, d.C, nullptr, nullptr, (void*)256, d.C, d.B, d.N, d.dtype);
+  b.w_bs = (int64_t)d.C * d.C;  // per-image C x C (M_b and its transpose)
+  mi_pw_desc q = attn_dqk_desc(d, (void*)256, 0, (void*)256, 0, (const float*)256, (void*)256, 0);
+  return max2(mi_pw_gemm_workspace(&b), mi_pw_gemm_workspace(&q));
+}
+
+// out = (residual?) + project_out(softmax(temperature * q^ k^T) v)        Restormer.py:121-131
+static int attn_core_fwd(const AttnDims& d, const QkvView& v, const float* temperature, const float* proj_w,
+                         const float* proj_b, const void* residual, void* out, const AttnSaved& sv, const AttnScratch& w,
+                         void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  mi_gram_desc g = attn_qk_gram(d, v, w.graw, w.ss);
+  MI_TRY(mi_gram(&g, w.gram_ws, stream));
+  MI_TRY(launch_attn_fold(w.graw, w.ss, temperature, proj_w, sv.P, sv.A, sv.nrm, sv.M, d.B, d.C, d.heads, st));
+  mi_pw_desc d2 = conv1x1(v.v, d.C, sv.M, false, d.C, proj_b, residual, out, d.C, d.B, d.N, d.dtype);
+  d2.x1_bs = v.v_bs;
+  d2.w_bs = (int64_t)d.C * d.C;
+  return mi_pw_gemm(&d2, w.pw_ws, stream);
+}
+
+// given dout: gradients w.r.t. q, k, v (written to the given channel slices) and temperature / project_out params
+static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, void* dq, int64_t dq_bs, void* dk,
+                         int64_t dk_bs, void* dv, int64_t dv_bs, const AttnSaved& sv, const float* temperature,
+                         const float* proj_w, float* g_temperature, float* g_proj_w, float* g_proj_b, int acc,
+                         const AttnScratch& w, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int B = d.B, C = d.C, hd = d.heads;
+  if (g_proj_b) MI_TRY(launch_chan_sum(dout, g_proj_b, B, C, d.N, d.dtype, acc, w.cs_ws, st));
+  mi_gram_desc g1 = attn_dm_gram(d, dout, v, w.dM);  // dM_b = dY V^T
+  MI_TRY(mi_gram(&g1, w.gram_ws, stream));
+  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, w.dwo_part, w.dtemp_part, w.wdq, w.wdk,
+                               w.attn_scr, B, C, hd, st));
+  MI_TRY(launch_reduce_rows(w.dwo_part, g_proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
+  MI_TRY(launch_reduce_rows(w.dtemp_part, g_temperature, B, hd, hd, acc, 1.0f, st));
+  // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
+  mi_pw_desc dd = attn_dqk_desc(d, v.k, v.k_bs, v.q, v.q_bs, w.wdq, dq, dq_bs);
+  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+  dd = attn_dqk_desc(d, v.q, v.q_bs, v.k, v.k_bs, w.wdk, dk, dk_bs);
+  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+  // dv = M_b^T dY
+  mi_pw_desc dvd = conv1x1(dout, C, sv.M, true, C, nullptr, nullptr, dv, C, B, d.N, d.dtype);
+  dvd.w_bs = (int64_t)C * C;
+  dvd.y_bs = dv_bs;
+  return mi_pw_gemm(&dvd, w.pw_ws, stream);
+}
+
+// ------------------------------------------------------------------ MDTA
+struct MdtaSaved { void* qkv0; void* qkv; AttnSaved at; size_t bytes; };
+static AttnDims mdta_dims(const mi_mdta_shape* s) { return AttnDims{s->B, s->C, s->heads, s->dtype, (int64_t)s->H * s->W}; }
+static MdtaSaved mdta_saved_layout(const mi_mdta_shape* s, void* base) {
+  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B;
+  Carver cv(base);
+  MdtaSaved r;
+  r.qkv0 = cv.take(tbytes(B * 3 * C * N, s->dtype));
+  r.qkv = cv.take(tbytes(B * 3 * C * N, s->dtype));
+  attn_saved_carve(cv, mdta_dims(s), &r.at);
+  r.bytes = cv.off;
+  return r;
+}
+static QkvView mdta_view(const mi_mdta_shape* s, const void* qkv) {
+  const int64_t N = (int64_t)s->H * s->W, bs = 3 * (int64_t)s->C * N;
+  const size_t es = dtype_size(s->dtype), plane = (size_t)s->C * N * es;
+  return QkvView{qkv, bs, (const char*)qkv + plane, bs, (const char*)qkv + 2 * plane, bs};
+}
+
+struct MdtaWs { AttnScratch at; MdtaSaved inf; void* dqkv; void* dqkv0; void* dw_ws; size_t bytes; };
 static MdtaWs mdta_ws_layout(const mi_mdta_shape* s, void* base) {
-  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B, c = C / s->heads, Z = B * s->heads;
+  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B;
+  const AttnDims d = mdta_dims(s);
   Carver cv(base);
   MdtaWs w;
-  w.graw = cv.take<float>(fbytes(Z * c * c));
-  w.ss = cv.take<float>(fbytes(Z * 2 * c));
-  w.dM = cv.take<float>(fbytes(B * C * C));
-  w.dwo_part = cv.take<float>(fbytes(B * C * C));
-  w.dtemp_part = cv.take<float>(fbytes(Z));
-  w.wdq = cv.take<float>(fbytes(Z * c * 2 * c));
-  w.wdk = cv.take<float>(fbytes(Z * c * 2 * c));
-  w.attn_scr = cv.take<float>(fbytes(attn_bwd_scratch_floats((int)B, (int)C, s->heads)));
-  // gram scratch: max over the three contractions this module runs
-  mi_gram_desc g1 = mdta_qk_gram(s, (void*)256, (float*)256, (float*)256);
-  mi_gram_desc g2 = mdta_dm_gram(s, (void*)256, (void*)256, (float*)256);
+  attn_scratch_carve(cv, d, &w.at);
   mi_gram_desc g3 = wgrad_gram((void*)256, 3 * (int)C, (void*)256, (int)C, (int)B, (int64_t)N, s->dtype, (float*)256, 0);
-  size_t gw = max2(mi_gram_workspace(&g1), max2(mi_gram_workspace(&g2), mi_gram_workspace(&g3)));
-  w.gram_ws = cv.take(gw);
-  {  // weight-pack scratch of the largest 1x1 GEMM of this module (qkv: 3C x C; per-image c x 2c and C x C slices)
+  w.at.gram_ws = cv.take(max2(attn_gram_ws_bytes(d), mi_gram_workspace(&g3)));
+  {  // weight-pack scratch of the largest 1x1 GEMM of this module
     mi_pw_desc a = conv1x1((void*)256, (int)C, (const float*)256, false, (int)C, nullptr, nullptr, (void*)256, 3 * (int)C,
                            (int)B, (int64_t)N, s->dtype);
-    mi_pw_desc b = a;
-    b.m = (int)C; b.w_bs = (int64_t)C * C;  // per-image C x C (M_b and its transpose)
-    mi_pw_desc d = a;
-    d.m = (int)c; d.k1 = (int)c; d.k2 = (int)c; d.x2 = (void*)256; d.groups = s->heads; d.w_bs = 1; d.w_gs = 1;
     mi_pw_desc e = conv1x1((void*)256, 3 * (int)C, (const float*)256, true, (int)C, nullptr, nullptr, (void*)256, (int)C,
                            (int)B, (int64_t)N, s->dtype);  // input gradient: W_qkv^T
-    w.pw_ws = cv.take(max2(max2(mi_pw_gemm_workspace(&a), mi_pw_gemm_workspace(&e)),
-                           max2(mi_pw_gemm_workspace(&b), mi_pw_gemm_workspace(&d))));
+    w.at.pw_ws = cv.take(max2(max2(mi_pw_gemm_workspace(&a), mi_pw_gemm_workspace(&e)), attn_pw_ws_bytes(d)));
   }
   w.dw_ws = cv.take(mi_dwconv_bwd_workspace((int)B, 3 * (int)C, s->H, s->W, s->ks));
-  w.cs_ws = cv.take(chan_sum_workspace(3 * (int)C, (int64_t)N));
+  w.at.cs_ws = cv.take(chan_sum_workspace(3 * (int)C, (int64_t)N));
   // big activation-sized buffers last: forward(inference) and backward never run concurrently on one blob
   size_t mark = cv.off;
   w.inf = mdta_saved_layout(s, base ? (char*)base + mark : nullptr);
@@ -135,6 +209,65 @@ static int mdta_check(const mi_mdta_shape* s) {
   MI_CHECK_ARG(s->C % s->heads == 0, "mdta: C=%d not divisible by heads=%d", s->C, s->heads);
   MI_CHECK_ARG(s->dtype == MI_F32 || s->dtype == MI_BF16, "mdta: bad dtype %d", s->dtype);
   MI_CHECK_ARG(s->ks == 3 || s->ks == 5 || s->ks == 7, "mdta: bad depthwise kernel size %d", s->ks);
+  return MI_OK;
+}
+
+// ------------------------------------------------------------------ cross-MDTA (q from x, k/v from y)
+struct XmdtaSaved { void* q0; void* q; void* kv0; void* kv; AttnSaved at; size_t bytes; };
+static AttnDims xmdta_dims(const mi_xmdta_shape* s) { return AttnDims{s->B, s->C, s->heads, s->dtype, (int64_t)s->H * s->W}; }
+static XmdtaSaved xmdta_saved_layout(const mi_xmdta_shape* s, void* base) {
+  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B;
+  Carver cv(base);
+  XmdtaSaved r;
+  r.q0 = cv.take(tbytes(B * C * N, s->dtype));
+  r.q = cv.take(tbytes(B * C * N, s->dtype));
+  r.kv0 = cv.take(tbytes(B * 2 * C * N, s->dtype));
+  r.kv = cv.take(tbytes(B * 2 * C * N, s->dtype));
+  attn_saved_carve(cv, xmdta_dims(s), &r.at);
+  r.bytes = cv.off;
+  return r;
+}
+static QkvView xmdta_view(const mi_xmdta_shape* s, const void* q, const void* kv) {
+  const int64_t N = (int64_t)s->H * s->W;
+  const size_t plane = (size_t)s->C * N * dtype_size(s->dtype);
+  return QkvView{q, (int64_t)s->C * N, kv, 2 * (int64_t)s->C * N, (const char*)kv + plane, 2 * (int64_t)s->C * N};
+}
+struct XmdtaWs { AttnScratch at; XmdtaSaved inf; void* dq; void* dq0; void* dkv; void* dkv0; void* dw_ws; size_t bytes; };
+static XmdtaWs xmdta_ws_layout(const mi_xmdta_shape* s, void* base) {
+  const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B;
+  const AttnDims d = xmdta_dims(s);
+  Carver cv(base);
+  XmdtaWs w;
+  attn_scratch_carve(cv, d, &w.at);
+  mi_gram_desc g3 = wgrad_gram((void*)256, 2 * (int)C, (void*)256, (int)C, (int)B, (int64_t)N, s->dtype, (float*)256, 0);
+  w.at.gram_ws = cv.take(max2(attn_gram_ws_bytes(d), mi_gram_workspace(&g3)));
+  {
+    mi_pw_desc a = conv1x1((void*)256, (int)C, (const float*)256, false, (int)C, nullptr, nullptr, (void*)256, 2 * (int)C,
+                           (int)B, (int64_t)N, s->dtype);
+    mi_pw_desc e = conv1x1((void*)256, 2 * (int)C, (const float*)256, true, (int)C, nullptr, nullptr, (void*)256, (int)C,
+                           (int)B, (int64_t)N, s->dtype);
+    w.at.pw_ws = cv.take(max2(max2(mi_pw_gemm_workspace(&a), mi_pw_gemm_workspace(&e)), attn_pw_ws_bytes(d)));
+  }
+  const int ksm = s->ks_q > s->ks_kv ? s->ks_q : s->ks_kv;
+  w.dw_ws = cv.take(mi_dwconv_bwd_workspace((int)B, 2 * (int)C, s->H, s->W, ksm));
+  w.at.cs_ws = cv.take(chan_sum_workspace(2 * (int)C, (int64_t)N));
+  size_t mark = cv.off;
+  w.inf = xmdta_saved_layout(s, base ? (char*)base + mark : nullptr);
+  Carver big(base ? (char*)base + mark : nullptr);
+  w.dq = big.take(tbytes(B * C * N, s->dtype));
+  w.dq0 = big.take(tbytes(B * C * N, s->dtype));
+  w.dkv = big.take(tbytes(B * 2 * C * N, s->dtype));
+  w.dkv0 = big.take(tbytes(B * 2 * C * N, s->dtype));
+  w.bytes = mark + max2(w.inf.bytes, big.off);
+  return w;
+}
+static int xmdta_check(const mi_xmdta_shape* s) {
+  MI_CHECK_ARG(s, "xmdta: null shape");
+  MI_CHECK_ARG(s->B > 0 && s->C > 0 && s->heads > 0 && s->H > 0 && s->W > 0, "xmdta: bad shape");
+  MI_CHECK_ARG(s->C % s->heads == 0, "xmdta: C=%d not divisible by heads=%d", s->C, s->heads);
+  MI_CHECK_ARG(s->dtype == MI_F32 || s->dtype == MI_BF16, "xmdta: bad dtype %d", s->dtype);
+  MI_CHECK_ARG((s->ks_q == 3 || s->ks_q == 5 || s->ks_q == 7) && (s->ks_kv == 3 || s->ks_kv == 5 || s->ks_kv == 7),
+               "xmdta: bad depthwise kernel sizes %d/%d", s->ks_q, s->ks_kv);
   return MI_OK;
 }
 
@@ -201,28 +334,16 @@ extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   MI_TRY(mdta_check(s));
   MI_CHECK_ARG(p && x && out && ws, "mdta_fwd: null pointer");
   MI_CHECK_ARG(p->temperature && p->qkv_w && p->dw_w && p->proj_w, "mdta_fwd: null parameter");
-  hipStream_t st = (hipStream_t)stream;
   const int B = s->B, C = s->C, dt = s->dtype;
   const int64_t N = (int64_t)s->H * s->W;
-  const size_t es = dtype_size(dt);
   MdtaWs w = mdta_ws_layout(s, ws);
   MdtaSaved sv = saved ? mdta_saved_layout(s, saved) : w.inf;
-
   // qkv0 = qkv(x);  qkv = dw(qkv0)                               Restormer.py:114
   mi_pw_desc d1 = conv1x1(x, C, p->qkv_w, false, C, p->qkv_b, nullptr, sv.qkv0, 3 * C, B, N, dt);
-  MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
+  MI_TRY(mi_pw_gemm(&d1, w.at.pw_ws, stream));
   MI_TRY(mi_dwconv_fwd(sv.qkv0, p->dw_w, p->dw_b, sv.qkv, B, 3 * C, s->H, s->W, s->ks, dt, stream));
-  // q k^T per head + row sums of squares                          Restormer.py:121-124
-  mi_gram_desc g = mdta_qk_gram(s, sv.qkv, w.graw, w.ss);
-  MI_TRY(mi_gram(&g, w.gram_ws, stream));
-  // normalise, temperature, softmax, fold project_out             Restormer.py:124-125,131
-  MI_TRY(launch_attn_fold(w.graw, w.ss, p->temperature, p->proj_w, sv.P, sv.A, sv.nrm, sv.M, B, C, s->heads, st));
-  // out = M_b v (+bias) (+residual)                               Restormer.py:127-131
-  mi_pw_desc d2 = conv1x1((const char*)sv.qkv + (size_t)2 * C * N * es, C, sv.M, false, C, p->proj_b, residual, out, C, B, N, dt);
-  d2.x1_bs = 3 * (int64_t)C * N;
-  d2.w_bs = (int64_t)C * C;
-  MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
-  return MI_OK;
+  return attn_core_fwd(mdta_dims(s), mdta_view(s, sv.qkv), p->temperature, p->proj_w, p->proj_b, residual, out, sv.at, w.at,
+                       stream);
 }
 
 extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* dout, void* dx,
@@ -231,51 +352,86 @@ extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   MI_CHECK_ARG(p && x && dout && dx && gr && saved && ws, "mdta_bwd: null pointer");
   MI_CHECK_ARG(gr->temperature && gr->qkv_w && gr->dw_w && gr->proj_w, "mdta_bwd: null gradient buffer");
   hipStream_t st = (hipStream_t)stream;
-  const int B = s->B, C = s->C, dt = s->dtype, hd = s->heads, c = C / hd, acc = gr->accumulate;
-  const int64_t N = (int64_t)s->H * s->W;
-  const size_t es = dtype_size(dt);
+  const int B = s->B, C = s->C, dt = s->dtype, acc = gr->accumulate;
+  const int64_t N = (int64_t)s->H * s->W, bs = 3 * (int64_t)C * N;
+  const size_t plane = (size_t)C * N * dtype_size(dt);
   MdtaWs w = mdta_ws_layout(s, ws);
   MdtaSaved sv = mdta_saved_layout(s, const_cast<void*>(saved));
-  const char* q = (const char*)sv.qkv;
-  const char* k = q + (size_t)C * N * es;
   char* dq = (char*)w.dqkv;
-  char* dk = dq + (size_t)C * N * es;
-  char* dv = dq + (size_t)2 * C * N * es;
-
-  if (gr->proj_b) MI_TRY(launch_chan_sum(dout, gr->proj_b, B, C, N, dt, acc, w.cs_ws, st));
-  // dM_b = dY V^T
-  mi_gram_desc g1 = mdta_dm_gram(s, dout, sv.qkv, w.dM);
-  MI_TRY(mi_gram(&g1, w.gram_ws, stream));
-  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, p->temperature, p->proj_w, w.dwo_part, w.dtemp_part, w.wdq, w.wdk,
-                               w.attn_scr, B, C, hd, st));
-  MI_TRY(launch_reduce_rows(w.dwo_part, gr->proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
-  MI_TRY(launch_reduce_rows(w.dtemp_part, gr->temperature, B, hd, hd, acc, 1.0f, st));
-  // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
-  mi_pw_desc dd;
-  memset(&dd, 0, sizeof(dd));
-  dd.x1 = k; dd.x1_bs = 3 * (int64_t)C * N; dd.x1_gs = (int64_t)c * N; dd.k1 = c;
-  dd.x2 = q; dd.x2_bs = dd.x1_bs; dd.x2_gs = dd.x1_gs; dd.k2 = c;
-  dd.w = w.wdq; dd.w_bs = (int64_t)hd * c * 2 * c; dd.w_gs = (int64_t)c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
-  dd.y = dq; dd.y_bs = 3 * (int64_t)C * N; dd.y_gs = (int64_t)c * N;
-  dd.m = c; dd.n = N; dd.batch = B; dd.groups = hd; dd.dtype = dt;
-  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
-  dd.x1 = q; dd.x2 = k; dd.w = w.wdk; dd.y = dk;
-  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
-  // dv = M_b^T dY
-  mi_pw_desc dvd = conv1x1(dout, C, sv.M, true, C, nullptr, nullptr, dv, C, B, N, dt);
-  dvd.w_bs = (int64_t)C * C;
-  dvd.y_bs = 3 * (int64_t)C * N;
-  MI_TRY(mi_pw_gemm(&dvd, w.pw_ws, stream));
+  MI_TRY(attn_core_bwd(mdta_dims(s), mdta_view(s, sv.qkv), dout, dq, bs, dq + plane, bs, dq + 2 * plane, bs, sv.at,
+                       p->temperature, p->proj_w, gr->temperature, gr->proj_w, gr->proj_b, acc, w.at, stream));
   // depthwise backward: d_qkv -> d_qkv0, weight/bias grads
   MI_TRY(mi_dwconv_bwd(w.dqkv, sv.qkv0, p->dw_w, w.dqkv0, gr->dw_w, gr->dw_b, B, 3 * C, s->H, s->W, s->ks, acc, dt, w.dw_ws,
                        stream));
   // qkv 1x1: weight grad (sum over batch), bias grad, input grad
   mi_gram_desc g2 = wgrad_gram(w.dqkv0, 3 * C, x, C, B, N, dt, gr->qkv_w, acc);
-  MI_TRY(mi_gram(&g2, w.gram_ws, stream));
-  if (gr->qkv_b) MI_TRY(launch_chan_sum(w.dqkv0, gr->qkv_b, B, 3 * C, N, dt, acc, w.cs_ws, st));
+  MI_TRY(mi_gram(&g2, w.at.gram_ws, stream));
+  if (gr->qkv_b) MI_TRY(launch_chan_sum(w.dqkv0, gr->qkv_b, B, 3 * C, N, dt, acc, w.at.cs_ws, st));
   mi_pw_desc dxd = conv1x1(w.dqkv0, 3 * C, p->qkv_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
-  MI_TRY(mi_pw_gemm(&dxd, w.pw_ws, stream));
-  return MI_OK;
+  return mi_pw_gemm(&dxd, w.at.pw_ws, stream);
+}
+
+extern "C" size_t mi_xmdta_saved_bytes(const mi_xmdta_shape* s) {
+  if (xmdta_check(s) != MI_OK) return 0;
+  return xmdta_saved_layout(s, nullptr).bytes;
+}
+extern "C" size_t mi_xmdta_workspace(const mi_xmdta_shape* s) {
+  if (xmdta_check(s) != MI_OK) return 0;
+  return xmdta_ws_layout(s, nullptr).bytes;
+}
+
+extern "C" int mi_xmdta_fwd(const mi_xmdta_shape* s, const mi_xmdta_params* p, const void* x, const void* y,
+                            const void* residual, void* out, void* saved, void* ws, void* stream) {
+  MI_TRY(xmdta_check(s));
+  MI_CHECK_ARG(p && x && y && out && ws, "xmdta_fwd: null pointer");
+  MI_CHECK_ARG(p->temperature && p->q_w && p->q_dw_w && p->kv_w && p->kv_dw_w && p->proj_w, "xmdta_fwd: null parameter");
+  const int B = s->B, C = s->C, dt = s->dtype;
+  const int64_t N = (int64_t)s->H * s->W;
+  XmdtaWs w = xmdta_ws_layout(s, ws);
+  XmdtaSaved sv = saved ? xmdta_saved_layout(s, saved) : w.inf;
+  // q = q_dwconv(q(x)) ; kv = kv_dwconv(kv(y))                    moce_ir.py:348-349, AdaIR-main/net/model.py:197-198
+  mi_pw_desc d1 = conv1x1(x, C, p->q_w, false, C, p->q_b, nullptr, sv.q0, C, B, N, dt);
+  MI_TRY(mi_pw_gemm(&d1, w.at.pw_ws, stream));
+  MI_TRY(mi_dwconv_fwd(sv.q0, p->q_dw_w, p->q_dw_b, sv.q, B, C, s->H, s->W, s->ks_q, dt, stream));
+  mi_pw_desc d2 = conv1x1(y, C, p->kv_w, false, C, p->kv_b, nullptr, sv.kv0, 2 * C, B, N, dt);
+  MI_TRY(mi_pw_gemm(&d2, w.at.pw_ws, stream));
+  MI_TRY(mi_dwconv_fwd(sv.kv0, p->kv_dw_w, p->kv_dw_b, sv.kv, B, 2 * C, s->H, s->W, s->ks_kv, dt, stream));
+  return attn_core_fwd(xmdta_dims(s), xmdta_view(s, sv.q, sv.kv), p->temperature, p->proj_w, p->proj_b, residual, out, sv.at,
+                       w.at, stream);
+}
+
+extern "C" int mi_xmdta_bwd(const mi_xmdta_shape* s, const mi_xmdta_params* p, const void* x, const void* y,
+                            const void* dout, void* dx, void* dy, const mi_xmdta_grads* gr, const void* saved, void* ws,
+                            void* stream) {
+  MI_TRY(xmdta_check(s));
+  MI_CHECK_ARG(p && x && y && dout && dx && dy && gr && saved && ws, "xmdta_bwd: null pointer");
+  MI_CHECK_ARG(gr->temperature && gr->q_w && gr->q_dw_w && gr->kv_w && gr->kv_dw_w && gr->proj_w,
+               "xmdta_bwd: null gradient buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, C = s->C, dt = s->dtype, acc = gr->accumulate;
+  const int64_t N = (int64_t)s->H * s->W;
+  const size_t plane = (size_t)C * N * dtype_size(dt);
+  XmdtaWs w = xmdta_ws_layout(s, ws);
+  XmdtaSaved sv = xmdta_saved_layout(s, const_cast<void*>(saved));
+  MI_TRY(attn_core_bwd(xmdta_dims(s), xmdta_view(s, sv.q, sv.kv), dout, w.dq, (int64_t)C * N, w.dkv, 2 * (int64_t)C * N,
+                       (char*)w.dkv + plane, 2 * (int64_t)C * N, sv.at, p->temperature, p->proj_w, gr->temperature,
+                       gr->proj_w, gr->proj_b, acc, w.at, stream));
+  // q branch
+  MI_TRY(mi_dwconv_bwd(w.dq, sv.q0, p->q_dw_w, w.dq0, gr->q_dw_w, gr->q_dw_b, B, C, s->H, s->W, s->ks_q, acc, dt, w.dw_ws,
+                       stream));
+  mi_gram_desc g1 = wgrad_gram(w.dq0, C, x, C, B, N, dt, gr->q_w, acc);
+  MI_TRY(mi_gram(&g1, w.at.gram_ws, stream));
+  if (gr->q_b) MI_TRY(launch_chan_sum(w.dq0, gr->q_b, B, C, N, dt, acc, w.at.cs_ws, st));
+  mi_pw_desc dxd = conv1x1(w.dq0, C, p->q_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
+  MI_TRY(mi_pw_gemm(&dxd, w.at.pw_ws, stream));
+  // kv branch
+  MI_TRY(mi_dwconv_bwd(w.dkv, sv.kv0, p->kv_dw_w, w.dkv0, gr->kv_dw_w, gr->kv_dw_b, B, 2 * C, s->H, s->W, s->ks_kv, acc, dt,
+                       w.dw_ws, stream));
+  mi_gram_desc g2 = wgrad_gram(w.dkv0, 2 * C, y, C, B, N, dt, gr->kv_w, acc);
+  MI_TRY(mi_gram(&g2, w.at.gram_ws, stream));
+  if (gr->kv_b) MI_TRY(launch_chan_sum(w.dkv0, gr->kv_b, B, 2 * C, N, dt, acc, w.at.cs_ws, st));
+  mi_pw_desc dyd = conv1x1(w.dkv0, 2 * C, p->kv_w, true, C, nullptr, nullptr, dy, C, B, N, dt);
+  return mi_pw_gemm(&dyd, w.at.pw_ws, stream);
 }
 
 extern "C" size_t mi_gdfn_saved_bytes(const mi_gdfn_shape* s) {

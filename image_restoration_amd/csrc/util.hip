@@ -25,7 +25,7 @@ static std::atomic<int> g_prof_on{0};
 static const char* const g_kernel_names[K_COUNT] = {
     "ln_fwd", "ln_bwd", "dwconv_fwd", "dwconv_gate_fwd", "dwconv_bwd_data", "dwconv_gate_bwd_data", "dwconv_wgrad",
     "pw_gemm", "gram", "gram_reduce", "attn_fold", "attn_bwd_small", "reduce_rows", "chan_sum", "adamw", "cast", "l1_loss",
-    "pw_pack"};
+    "pw_pack", "gap"};
 
 ProfScope::ProfScope(hipStream_t stream, int kernel_id, double bytes, double flops)
     : st(stream), kid(kernel_id), on(g_prof_on.load(std::memory_order_relaxed) != 0) {
@@ -135,6 +135,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// Global average pool of the MoCE router (moce_ir.py:703-707 AdaptiveAvgPool2d(1)): one workgroup per (image, channel).
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t N) {
+  __shared__ float sm[4];
+  const T* row = x + (int64_t)blockIdx.x * N;
+  float acc = 0.f;
+  for (int64_t n = threadIdx.x; n < N; n += 256) acc += to_f32(row[n]);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)N;
+}
+// dx[b,c,:] = dout[b,c] / N
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dx, int64_t N) {
+  const float v = dout[blockIdx.x] / (float)N;
+  T* row = dx + (int64_t)blockIdx.x * N;
+  for (int64_t n = threadIdx.x; n < N; n += 256) row[n] = Cvt<T>::from(v);
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -201,6 +221,27 @@ extern "C" int mi_adamw_step(float* p, const float* g, float* m, float* v, int64
   ProfScope ps((hipStream_t)stream, K_ADAMW, 28.0 * n, 12.0 * n);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2, grad_scale, dev_scalars);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtype, void* stream) {
+  MI_CHECK_ARG(x && out && B > 0 && C > 0 && N > 0, "gap_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_GAP, (double)B * C * N * dtype_size(dtype), (double)B * C * N);
+  if (dtype == MI_F32) hipLaunchKernelGGL((gap_fwd_kernel<float>), dim3(B * C), dim3(256), 0, st, (const float*)x, out, N);
+  else if (dtype == MI_BF16) hipLaunchKernelGGL((gap_fwd_kernel<bf16>), dim3(B * C), dim3(256), 0, st, (const bf16*)x, out, N);
+  else { set_error("gap_fwd: bad dtype"); return MI_ERR_ARG; }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+extern "C" int mi_gap_bwd(const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream) {
+  MI_CHECK_ARG(dout && dx && B > 0 && C > 0 && N > 0, "gap_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_GAP, (double)B * C * N * dtype_size(dtype), 0.0);
+  if (dtype == MI_F32) hipLaunchKernelGGL((gap_bwd_kernel<float>), dim3(B * C), dim3(256), 0, st, dout, (float*)dx, N);
+  else if (dtype == MI_BF16) hipLaunchKernelGGL((gap_bwd_kernel<bf16>), dim3(B * C), dim3(256), 0, st, dout, (bf16*)dx, N);
+  else { set_error("gap_bwd: bad dtype"); return MI_ERR_ARG; }
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -228,6 +228,46 @@ def mdta_bwd(x: Tensor, dout: Tensor, params: MdtaParamsT, heads: int, saved: Te
     return dx
 
 
+def _xmdta_shape(x: Tensor, heads: int, ks_q: int, ks_kv: int) -> L.XmdtaShape:
+    B, Cc, H, W = x.shape
+    return L.XmdtaShape(B, Cc, heads, H, W, _dt(x), ks_q, ks_kv)
+
+
+def xmdta_fwd(x: Tensor, y: Tensor, residual: Optional[Tensor], params: Sequence[Optional[Tensor]], heads: int,
+              need_saved: bool):
+    """Cross-MDTA.  params = (temperature, q.weight, q.bias, q_dwconv.weight, q_dwconv.bias, kv.weight, kv.bias,
+    kv_dwconv.weight, kv_dwconv.bias, project_out.weight, project_out.bias)."""
+    _gpu(x, y, residual, *params)
+    assert x.shape == y.shape and x.dtype == y.dtype, "cross-MDTA needs x and y of one shape and dtype"
+    for t in params:
+        _f32(t, "cross-MDTA parameter")
+    s = _xmdta_shape(x, heads, params[3].shape[-1], params[7].shape[-1])
+    lib = L.lib()
+    out = torch.empty_like(x)
+    saved = _blob(lib.mi_xmdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
+    ws = _blob(lib.mi_xmdta_workspace(C.byref(s)), x.device)
+    pp = L.XmdtaParams(*[_p(t) for t in params])
+    L.check(lib.mi_xmdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(y), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
+            "xmdta_fwd")
+    return out, saved
+
+
+def xmdta_bwd(x: Tensor, y: Tensor, dout: Tensor, params: Sequence[Optional[Tensor]], heads: int, saved: Tensor,
+              grads: Sequence[Optional[Tensor]], accumulate: bool):
+    _gpu(x, y, dout, saved, *params, *grads)
+    s = _xmdta_shape(x, heads, params[3].shape[-1], params[7].shape[-1])
+    lib = L.lib()
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    ws = _blob(lib.mi_xmdta_workspace(C.byref(s)), x.device)
+    pp = L.XmdtaParams(*[_p(t) for t in params])
+    for t in grads:
+        _f32(t, "cross-MDTA gradient")
+    gg = L.XmdtaGrads(*[_p(t) for t in grads], int(accumulate))
+    L.check(lib.mi_xmdta_bwd(C.byref(s), C.byref(pp), _p(x), _p(y), _p(dout), _p(dx), _p(dy), C.byref(gg), _p(saved), _p(ws),
+                             _stream()), "xmdta_bwd")
+    return dx, dy
+
+
 def _gdfn_shape(x: Tensor, hidden: int, ks: int) -> L.GdfnShape:
     B, Cc, H, W = x.shape
     return L.GdfnShape(B, Cc, hidden, H, W, _dt(x), ks)
@@ -264,6 +304,23 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
     gg = L.GdfnGrads(*[_p(t) for t in grads], int(accumulate))
     L.check(lib.mi_gdfn_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
             "gdfn_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- router GAP
+def gap_fwd(x: Tensor) -> Tensor:
+    _gpu(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.lib().mi_gap_fwd(_p(x), _p(out), B, Cc, H * W, _dt(x), _stream()), "gap_fwd")
+    return out
+
+
+def gap_bwd(dout: Tensor, like: Tensor) -> Tensor:
+    _gpu(dout, like)
+    B, Cc, H, W = like.shape
+    dx = torch.empty_like(like)
+    L.check(L.lib().mi_gap_bwd(_p(dout.contiguous().float()), _p(dx), B, Cc, H * W, _dt(like), _stream()), "gap_bwd")
     return dx
 
 

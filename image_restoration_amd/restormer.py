@@ -156,6 +156,53 @@ class _BlockFn(torch.autograd.Function):
         return (dx, None) + tuple(None if acc else g for g in grads)
 
 
+class _CrossAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, heads, *params):
+        need = any(ctx.needs_input_grad)
+        out, saved = ops.xmdta_fwd(x, y, None, params, heads, need)
+        if need:
+            ctx.heads = heads
+            ctx.mg = _main_grads(params)
+            ctx.present = [p is not None for p in params]
+            ctx.save_for_backward(x, y, saved, *[p for p in params if p is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, saved, *rest = ctx.saved_tensors
+        it = iter(rest)
+        params = tuple(next(it) if pr else None for pr in ctx.present)
+        acc = ctx.mg is not None
+        grads = ctx.mg if acc else _fresh_grads(params)
+        dx, dy = ops.xmdta_bwd(x, y, dout.contiguous(), params, ctx.heads, saved, grads, acc)
+        return (dx, dy, None) + tuple(None if acc else g for g in grads)
+
+
+class _DwConvFn(torch.autograd.Function):
+    """Stand-alone depthwise k x k conv (stride 1, pad k/2): moce_ir.py:377-381 FFTAttention q_dwconv / kv_dwconv."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.dwconv_fwd(x, weight, bias)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, weight)
+            ctx.has_bias = bias is not None
+            ctx.mg = _main_grads((weight, bias))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = ops.dwconv_bwd(dy.contiguous(), x, weight, ctx.has_bias)
+        if ctx.mg is not None:
+            ctx.mg[0].add_(dw)
+            if ctx.has_bias:
+                ctx.mg[1].add_(db)
+            return dx, None, None
+        return dx, dw, db
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     """1x1 conv over an optional channel concat [x1 ; x2] without materialising the concat
     (Restormer.py:223,228 reduce_chan_level{3,2} applied to torch.cat, :259-266)."""

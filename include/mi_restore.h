@@ -153,6 +153,29 @@ int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, 
                 void* dx, const mi_mdta_grads* g, const void* saved, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Cross-MDTA: q from x (1x1 C->C + depthwise ks_q), k,v from y (1x1 C->2C + depthwise ks_kv), then the
+ * MDTA core.  moce_ir.py:325-368 CrossAttention (ks_q 3, ks_kv 7); AdaIR-main/net/model.py:177-216
+ * Chanel_Cross_Attention (3, 3).  bwd returns dx and dy.
+ * ------------------------------------------------------------------------ */
+typedef struct { int B, C, heads, H, W, dtype, ks_q, ks_kv; } mi_xmdta_shape;
+typedef struct {
+  const float* temperature;
+  const float* q_w;  const float* q_b;  const float* q_dw_w;  const float* q_dw_b;     /* [C,C] [C] [C,ks_q^2] [C] */
+  const float* kv_w; const float* kv_b; const float* kv_dw_w; const float* kv_dw_b;    /* [2C,C] [2C] [2C,ks_kv^2] [2C] */
+  const float* proj_w; const float* proj_b;
+} mi_xmdta_params;
+typedef struct {
+  float* temperature; float* q_w; float* q_b; float* q_dw_w; float* q_dw_b; float* kv_w; float* kv_b; float* kv_dw_w;
+  float* kv_dw_b; float* proj_w; float* proj_b; int accumulate;
+} mi_xmdta_grads;
+size_t mi_xmdta_saved_bytes(const mi_xmdta_shape* s);
+size_t mi_xmdta_workspace(const mi_xmdta_shape* s);
+int mi_xmdta_fwd(const mi_xmdta_shape* s, const mi_xmdta_params* p, const void* x, const void* y,
+                 const void* residual, void* out, void* saved, void* ws, void* stream);
+int mi_xmdta_bwd(const mi_xmdta_shape* s, const mi_xmdta_params* p, const void* x, const void* y, const void* dout,
+                 void* dx, void* dy, const mi_xmdta_grads* g, const void* saved, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------
  * GDFN — FeedForward.forward / backward (Restormer.py:76-93; moce_ir.py:255-276;
  * AdaIR-main/net/model.py:76-94).  hidden = h (project_in has 2h outputs).
  * ------------------------------------------------------------------------ */
@@ -180,6 +203,13 @@ int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, 
 int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale,
                   const float* dev_scalars, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Router global average pool (moce_ir.py:703-707, RoutingFunction.gate[0]): out[b,c] = mean_n x[b,c,n] (fp32);
+ * bwd: dx[b,c,:] = dout[b,c]/N.
+ * ------------------------------------------------------------------------ */
+int mi_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtype, void* stream);
+int mi_gap_bwd(const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream);
 
 /* dtype conversion / L1 loss helpers used by the harness */
 int mi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

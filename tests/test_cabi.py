@@ -73,6 +73,23 @@ def test_state_dict_matches_reference_and_cpu_is_refused(lib):
         m.LayerNorm(48, "WithBias")(torch.zeros(1, 48, 8, 8))
 
 
+def test_moce_and_adair_state_dict_keys_match_reference(lib):
+    """Key lists captured from the reference modules (tools/capture_golden_moce.py) vs the drop-in modules."""
+    import image_restoration_amd.adair as ad
+    import image_restoration_amd.moce_ir as mo
+    from oracle.fixtures import load
+    gold = load("moce_keys")
+    db = mo.DecoderBlock(dim=48, num_heads=1, ffn_expansion_factor=2, bias=False, LayerNorm_type="WithBias",
+                         expert_layer=mo.FFTAttention, complexity_scale="max", rank=2, num_experts=4, top_k=1,
+                         depth_type="constant", rank_type="spread", stage_depth=1, freq_dim=64, with_complexity=True)
+    assert list(db.state_dict()) == [str(k) for k in gold["decoder"]]
+    assert list(mo.EncoderBlock(48, 2, 2, True, "WithBias").state_dict()) == [str(k) for k in gold["encoder"]]
+    assert list(mo.CrossAttention(48, 1, True).state_dict()) == [str(k) for k in gold["cross"]]
+    assert list(ad.Chanel_Cross_Attention(48, 4, False).state_dict()) == [str(k) for k in gold["adair_cross"]]
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        mo.CrossAttention(48, 1, True)(torch.zeros(1, 48, 8, 8), torch.zeros(1, 48, 8, 8))
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "image_restoration_amd")
     for dp, _, files in os.walk(pkg):

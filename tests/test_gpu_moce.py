@@ -1,0 +1,138 @@
+"""GPU parity of the MoCE-IR / AdaIR drop-in modules against the reference's golden vectors
+(tools/capture_golden_moce.py) and the fp64 oracle.  fp32 activations, 1e-3 relative (north_star bar)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import moce_ref as MR
+from oracle import restormer_ref as R
+from oracle.fixtures import check, load, seeded_input
+from test_oracle_golden_moce import cross_shapes, decoder_state, encoder_shapes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def run(mod, inputs, seed, call=None):
+    mod = mod.to(DEV)
+    ins = [t.to(DEV).requires_grad_(True) for t in inputs]
+    y = (call or mod)(*ins)
+    y0 = y[0] if isinstance(y, tuple) else y
+    y0.backward(seeded_input(tuple(y0.shape), seed + 1000).to(DEV))
+    return y, [t.grad for t in ins], {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+
+
+class injected_noise:
+    def __init__(self, seed):
+        self.seed = seed
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        seed = self.seed
+        torch.randn_like = lambda t, **kw: seeded_input(tuple(t.shape), seed, torch.float64).to(t.dtype).to(t.device)
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
+@pytest.mark.parametrize("tag,c,heads", [("moce_cross_c48h1", 48, 1), ("moce_cross_c96h2", 96, 2)])
+def test_cross_attention_moce(tag, c, heads):
+    import image_restoration_amd.moce_ir as mo
+    m = mo.CrossAttention(c, heads, True)
+    m.load_state_dict(R.make_state(cross_shapes(c, heads, True, 7), 60 + c))
+    x, y = seeded_input((2, c, 16, 16), 600 + c), seeded_input((2, c, 16, 16), 601 + c)
+    out, (dx, dy), g = run(m, [x, y], 610)
+    gold = load(tag)
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3); check("dy", dy, gold, 1e-3)
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3)
+
+
+def test_cross_attention_adair():
+    import image_restoration_amd.adair as ad
+    m = ad.Chanel_Cross_Attention(48, 4, False)
+    m.load_state_dict(R.make_state(cross_shapes(48, 4, False, 3), 65))
+    x, y = seeded_input((2, 48, 16, 16), 650), seeded_input((2, 48, 16, 16), 651)
+    out, (dx, dy), g = run(m, [x, y], 660)
+    gold = load("adair_cross_c48h4")
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3); check("dy", dy, gold, 1e-3)
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3)
+    with pytest.raises(AssertionError):
+        m(x.to(DEV), y[:, :, :8].contiguous().to(DEV))
+
+
+def test_encoder_block():
+    import image_restoration_amd.moce_ir as mo
+    m = mo.EncoderBlock(48, 2, 2, True, "WithBias")
+    m.load_state_dict(R.make_state(encoder_shapes(48, 2, 2, True), 75))
+    out, (dx,), g = run(m, [seeded_input((2, 48, 16, 16), 750)], 760)
+    gold = load("moce_encoder_c48h2")
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3)
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_routing_and_dispatcher(k):
+    import image_restoration_amd.moce_ir as mo
+    gold = load(f"moce_routing_k{k}")
+    comp = torch.tensor([18840., 42288., 103008., 279744.])
+    rf = mo.RoutingFunction(48, 64, num_experts=4, k=k, complexity=comp, use_complexity_bias=True, complexity_scale="max")
+    rf.load_state_dict(R.make_state({"gate.2.weight": (4, 48), "freq_gate.weight": (4, 64)}, 70 + k), strict=False)
+    rf = rf.to(DEV).train()
+    x, fe = seeded_input((8, 48, 8, 8), 700).to(DEV), seeded_input((8, 64), 701).to(DEV)
+    with injected_noise(702):
+        gates, idx, vals, aux = rf(x, fe)
+    check("gates", gates, gold, 1e-4)
+    assert np.array_equal(idx.cpu().numpy(), gold["idx"])
+    assert abs(float(aux) - float(gold["aux"])) < 1e-4
+    disp = mo.SparseDispatcher(4, gates)
+    parts = disp.dispatch(x)
+    assert [p.shape[0] for p in parts] == list(gold["part_sizes"])
+    comb = disp.combine([p * (e + 1) for e, p in enumerate(parts)], multiply_by_gates=True)
+    assert comb.dtype == torch.float32
+    check("combined", comb, gold, 1e-4)
+
+
+def test_decoder_block_train_and_eval():
+    gold = load("moce_decoder_train")
+    m, sd = decoder_state(torch.float32)
+    m.load_state_dict(sd, strict=False)
+    assert np.allclose(m.adapter.routing.complexity.numpy(), gold["complexity"])
+    x, fe = seeded_input((4, 48, 16, 16), 800), seeded_input((4, 64), 801)
+    m.train()
+    with injected_noise(802):
+        (out, aux), (dx, dfe), g = run(m, [x, fe], 810)
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3)
+    assert abs(float(aux) - float(gold["aux"])) < 1e-4
+    for k, v in g.items():
+        if float(gold["g_" + k + ".l2"]) < 1e-6:      # router weights: no gradient through the main path at top_k = 1
+            assert float(v.norm()) < 1e-5, k
+            continue
+        check("g_" + k, v, gold, 2e-3, what="decoder ")
+    m.eval()
+    gold_e = load("moce_decoder_eval")
+    with torch.no_grad(), injected_noise(803):
+        out_e, aux_e = m(x[:1].to(DEV), fe[:1].to(DEV))
+    check("y", out_e, gold_e, 1e-3)
+    assert aux_e == 0
+
+
+def test_decoder_block_bf16_runs():
+    """bf16 activations through the whole MoCE decoder block (experts' FFT part runs in fp32 as in the reference)."""
+    m, sd = decoder_state(torch.float32)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).train()
+    x = seeded_input((4, 48, 16, 16), 800).to(DEV).bfloat16().requires_grad_(True)
+    fe = seeded_input((4, 64), 801).to(DEV)
+    with injected_noise(802):
+        out, aux = m(x, fe)
+    assert out.dtype == torch.bfloat16
+    out.float().mean().backward()
+    ref, _ = MR.decoder_block(x.detach().float().cpu().double(), fe.cpu().double(), {k: v.double() for k, v in sd.items()}, 1,
+                              dict(dim=48, rank=2, num_experts=4, top_k=1, rank_type="spread", with_complexity=True,
+                                   complexity=m.adapter.routing.complexity.cpu().double()),
+                              seeded_input((4, 4), 802, torch.float64), True)
+    err = float((out.float().cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-2, err
