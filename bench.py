@@ -235,7 +235,8 @@ def main():
                                    f"AdamW, {args.patch}x{args.patch} patches, bs {batch}/GPU, {args.dtype} activations, "
                                    f"fp32 params/grads/optimizer",
                        "per_gpu_batch": batch, "global_batch": batch * world, "patch": args.patch,
-                       "parallelism": f"dp{world}", "hip_graph": bool(graph is not None), "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "hip_graph": bool(graph is not None), "final_loss": final_loss,
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -1,0 +1,101 @@
+"""World-size-2 gloo test of the data-parallel trainer (image_restoration_amd/trainer.py): two ranks on half batches
+must end with the same parameters as one process on the whole batch with torch.optim.AdamW — which checks the flat
+parameter/gradient buffers, the stage-bucketed all-reduce launched from the backward hooks (overlap=True) and after
+backward (overlap=False), the folding of autograd-delivered gradients and the AdamW update.  CPU only; the blocks of
+the stand-in network are plain torch layers because the HIP modules refuse CPU tensors by design."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class TinyNet(nn.Module):
+    """Three parameterised stages plus a parameter-free one and a skip connection, like the U-Net's top level."""
+
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Conv2d(3, 8, 3, padding=1)
+        self.enc = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1), nn.GELU(), nn.Conv2d(8, 8, 1))
+        self.pool = nn.Identity()
+        self.dec = nn.Sequential(nn.Conv2d(16, 8, 1), nn.GELU())
+        self.out = nn.Conv2d(8, 3, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        e = self.embed(x)
+        h = self.pool(self.enc(e))
+        d = self.dec(torch.cat([h, e], 1))
+        return self.out(d) + x
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, overlap, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_restoration_amd.trainer import FlatTrainer
+        torch.manual_seed(0)
+        model = TinyNet()
+        tr = FlatTrainer(model, lr=1e-2, overlap=overlap)
+        assert tr.world == world and len(tr.stages) == 4
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(4, 3, 8, 8, generator=g)
+        y = torch.randn(4, 3, 8, 8, generator=g)
+        xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+        for _ in range(3):
+            tr.zero_grad()
+            loss = (model(xs) - ys).abs().mean()
+            loss.backward()
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        if rank == 0:
+            ret["params"] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            ret["stages"] = [(n, lo, hi) for n, _, lo, hi in tr.stages]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_training_matches_single_process(overlap):
+    torch.manual_seed(0)
+    ref = TinyNet()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randn(4, 3, 8, 8, generator=g)
+    for _ in range(3):
+        opt.zero_grad()
+        (ref(x) - y).abs().mean().backward()
+        opt.step()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), overlap, ret), nprocs=2, join=True)
+    got = ret["params"]
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(got[k], v, rtol=1e-5, atol=1e-6), k
+    # flat ranges of the stages are disjoint and ordered by registration
+    spans = sorted((lo, hi) for _, lo, hi in ret["stages"])
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_cosine_warmup_schedule_closed_form():
+    """LinearWarmupCosineAnnealingLR(warmup 15, max 150) closed form (MoCE-IR-main/src/utils/schedulers.py:332-346):
+    hand-computed points."""
+    import math
+    from image_restoration_amd.trainer import cosine_warmup_lr
+    assert cosine_warmup_lr(0, 2e-4) == 0.0
+    assert abs(cosine_warmup_lr(7, 2e-4) - 7 * 2e-4 / 14) < 1e-15
+    assert abs(cosine_warmup_lr(14, 2e-4) - 2e-4) < 1e-15
+    assert abs(cosine_warmup_lr(15, 2e-4) - 2e-4) < 1e-15
+    mid = 15 + (150 - 15) / 2
+    assert abs(cosine_warmup_lr(mid, 2e-4) - 1e-4) < 1e-12
+    assert abs(cosine_warmup_lr(150, 2e-4)) < 1e-15
+    assert abs(cosine_warmup_lr(60, 2e-4) - 0.5 * 2e-4 * (1 + math.cos(math.pi * 45 / 135))) < 1e-15
