@@ -147,6 +147,8 @@ def main():
             use_graph = False
             torch.cuda.synchronize()
             step, loss_buf = make_step(model, trainer, noisy, clean, use_dev_scalars=False)
+    else:
+        run_eager(2)  # allocator settle: the first steps hipMalloc ~4 GB of activations per image (never timed)
 
     def one():
         if graph is not None:
