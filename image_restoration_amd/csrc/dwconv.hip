@@ -91,13 +91,22 @@ template <typename G, int TW> struct DwStage {
   static constexpr int NV = (G::LH * VPR + 255) / 256;        // vectors per thread
 };
 
+// threadIdx.x through an opaque move: inside the x-tile loops this keeps everything derived from the thread id (row /
+// vector indices, LDS offsets) from being hoisted out of the loop and held in VGPRs for the whole kernel.
+__device__ __forceinline__ int dw_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 template <typename T, typename G, int TW, int MODE>
 __device__ __forceinline__ void dw_load_vecs(const DwArgs& a, int b, int cc, int y0, int x0, bool vec_ok,
                                              float (*o)[4]) {
   using S = DwStage<G, TW>;
+  const int tid = dw_tid();
 #pragma unroll
   for (int i = 0; i < S::NV; ++i) {
-    const int e = threadIdx.x + 256 * i;
+    const int e = tid + 256 * i;
     const int r = e / S::VPR, v = e - r * S::VPR;
     const int gy = y0 - G::P + r, gx = x0 + 4 * v;
     o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
@@ -108,9 +117,10 @@ __device__ __forceinline__ void dw_load_vecs(const DwArgs& a, int b, int cc, int
 template <typename G, int TW>
 __device__ __forceinline__ void dw_write_vecs(float* tile, const float (*o)[4]) {
   using S = DwStage<G, TW>;
+  const int tid = dw_tid();
 #pragma unroll
   for (int i = 0; i < S::NV; ++i) {
-    const int e = threadIdx.x + 256 * i;
+    const int e = tid + 256 * i;
     if (e < G::LH * S::VPR) {
       const int r = e / S::VPR, v = e - r * S::VPR;
       float* d = tile + r * G::LW + G::P + 4 * v;
@@ -121,7 +131,7 @@ __device__ __forceinline__ void dw_write_vecs(float* tile, const float (*o)[4]) 
 
 template <typename T, typename G, int TW, int MODE>
 __device__ __forceinline__ void dw_stage_halo(float* tile, const DwArgs& a, int b, int cc, int y0, int x0) {
-  for (int e = threadIdx.x; e < G::LH * 2 * G::P; e += 256) {
+  for (int e = dw_tid(); e < G::LH * 2 * G::P; e += 256) {
     const int r = e / (2 * G::P), hcol = e - r * (2 * G::P);
     const int c = hcol < G::P ? hcol : TW + hcol;  // left halo cols [0,P), right halo cols [TW+P, TW+2P)
     const int gy = y0 - G::P + r, gx = x0 - G::P + c;
@@ -183,21 +193,31 @@ __device__ __forceinline__ void dw_store4(T* plane, int H, int W, int y, int x, 
   }
 }
 
+#define DW_OPAQUE(v) asm volatile("" : "+s"(v))
+
 // forward.  GATE: blockIdx.y indexes the hidden channel j; planes j and j+hidden are convolved,
 // y (optional) gets both, g = gelu(y1)*y2.
 template <typename T, int KS, int TW, int RPT, bool GATE>
-__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GATE && KS == 3 ? 4 : 1)))
+void dwconv_kernel(DwArgs a, int vec_ok) {
   using G = DwGeom<KS, TW, RPT>;
   __shared__ __attribute__((aligned(16))) float tile[(GATE ? 2 : 1) * G::LH * G::LW];
   __shared__ float wsm[(GATE ? 2 : 1) * KS * KS];
-  const int tile_id = blockIdx.x;
-  const int x0 = (tile_id % a.tiles_x) * TW, y0 = (tile_id / a.tiles_x) * G::TH;
+  // One workgroup = one ROW BAND of a plane; it walks the band's x-tiles left to right, so the halo columns of a tile
+  // are lines this CU has just read (or reads next) as interior: measured with FETCH_SIZE, independent 64-wide tiles
+  // pulled 2.3x their algorithmic reads through the fabric (two extra 128-byte lines per row).
+  const int y0_band = blockIdx.x * G::TH;
   const int cc = blockIdx.y, b = blockIdx.z;
-  const int tx = threadIdx.x % G::TXN, ty = threadIdx.x / G::TXN;
   if (threadIdx.x < KS * KS) {
     wsm[threadIdx.x] = a.w[(int64_t)cc * KS * KS + threadIdx.x];
     if (GATE) wsm[KS * KS + threadIdx.x] = a.w[(int64_t)(cc + a.hidden) * KS * KS + threadIdx.x];
   }
+ for (int txi = 0; txi < a.tiles_x; ++txi) {
+  const int x0 = txi * TW;
+  int y0 = y0_band;
+  DW_OPAQUE(y0);             // keeps the per-thread row addresses out of loop-invariant hoisting (it doubled the VGPRs)
+  const int tid_c = dw_tid(), tx = tid_c % G::TXN, ty = tid_c / G::TXN;
+  if (txi) __syncthreads();  // everyone is done with the previous tile's LDS image
   {
     float va[DwStage<G, TW>::NV][4], vb[GATE ? DwStage<G, TW>::NV : 1][4];
     dw_load_vecs<T, G, TW, IN_PLAIN>(a, b, cc, y0, x0, vec_ok, va);
@@ -234,11 +254,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a, int vec_ok) {
       dw_store4<T>((T*)a.gate + ((int64_t)b * a.hidden + cc) * HW, a.H, a.W, oy + r, ox, g, vec_ok);
     }
   }
+ }  // x-tiles
 }
 
 // Backward: dx = dw^T(dy) (flipped taps over the dy tile) and, from the same staged dy tile plus the x tile,
 //   dW[c][ky][kx] partial = sum_{tile pixels} dy[y][x] * x[y+ky-P][x+kx-P],  db partial = sum dy.
-// grid (tiles, Cc, B); block partial -> part[b*tiles + tile][Cc*KK | Cc].  WANT_DX / WANT_DW select the halves.
+// grid (bands, Cc, B); block partial -> part[b*bands + band][Cc*KK | Cc].  WANT_DX / WANT_DW select the halves.
 template <typename T, int KS, int TW, int RPT, int MODE, bool WANT_DX, bool WANT_DW>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __restrict__ xin, float* __restrict__ part,
                                                          int vec_ok) {
@@ -249,12 +270,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
   __shared__ __attribute__((aligned(16))) float xt[WANT_DW ? G::LH * G::LW : 1];
   __shared__ float wsm[KK];
   __shared__ float red[4][KK + 1];
-  const int tile_id = blockIdx.x, tiles = gridDim.x;
-  const int x0 = (tile_id % dya.tiles_x) * TW, y0 = (tile_id / dya.tiles_x) * G::TH;
+  const int band = blockIdx.x, bands = gridDim.x;   // one row band per workgroup, x-tiles walked in order (see dwconv_kernel)
+  const int y0_band = band * G::TH;
   const int cc = blockIdx.y, b = blockIdx.z;
-  const int tx = threadIdx.x % G::TXN, ty = threadIdx.x / G::TXN;
-  const int oy = y0 + RPT * ty, ox = x0 + 4 * tx;
   if (threadIdx.x < KK) wsm[threadIdx.x] = dya.w[(int64_t)cc * KK + threadIdx.x];
+  float acc[KK + 1];
+#pragma unroll
+  for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
+ for (int txi = 0; txi < dya.tiles_x; ++txi) {
+  int y0 = y0_band;
+  DW_OPAQUE(y0);
+  const int tid_c = dw_tid(), tx = tid_c % G::TXN, ty = tid_c / G::TXN;
+  const int x0 = txi * TW, ox = x0 + 4 * tx, oy = y0 + RPT * ty;
+  if (txi) __syncthreads();
   {
     DwArgs xa = dya;
     xa.in = xin;
@@ -276,9 +304,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
       dw_store4<T>((T*)dya.out + ((int64_t)b * dya.Cc + cc) * HW, dya.H, dya.W, oy + r, ox, o[r], vec_ok);
   }
   if (WANT_DW) {
-    float acc[KK + 1];
-#pragma unroll
-    for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
     // the thread's dy values (tile centre; out-of-image entries of the staged tile are already zero)
     float d[RPT][4];
 #pragma unroll
@@ -302,6 +327,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
           for (int j = 0; j < 4; ++j) acc[ky * KS + kx] += d[r][j] * row[j + kx];
       }
     }
+  }
+ }  // x-tiles
+  if (WANT_DW) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i <= KK; ++i) {
@@ -312,7 +340,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
     if (threadIdx.x <= KK) {
       const int i = threadIdx.x;
       const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-      float* prow = part + ((int64_t)b * tiles + tile_id) * ((int64_t)dya.Cc * (KK + 1));
+      float* prow = part + ((int64_t)b * bands + band) * ((int64_t)dya.Cc * (KK + 1));
       if (i < KK) prow[(int64_t)cc * KK + i] = s;
       else prow[(int64_t)dya.Cc * KK + cc] = s;
     }
@@ -323,7 +351,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwArgs dya, const T* __
 //   d1 = dg * y2 * gelu'(y1)  (gradient of conv output j),   d2 = dg * gelu(y1)  (gradient of conv output j+h)
 // are formed once per pixel from one read of (dg, y1, y2), staged as two dy tiles, and pushed through the transposed
 // depthwise conv of planes j and j+h; the weight/bias gradient partials of both planes come from the same tiles.
-// grid (tiles, hidden, B); LDS holds 4 tiles, so the tile is 2 rows per thread.
+// grid (bands, hidden, B); LDS holds 4 tiles, so the tile is 2 rows per thread.
 template <typename T, int KS, int TW, int RPT, bool WANT_DW>
 __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
                                                               int vec_ok) {
@@ -338,11 +366,9 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
   __shared__ __attribute__((aligned(16))) float x2t[WANT_DW ? TSZ : 1];
   __shared__ float wsm[2 * KK];
   __shared__ float red[4][2 * (KK + 1)];
-  const int tile_id = blockIdx.x, tiles = gridDim.x;
-  const int x0 = (tile_id % a.tiles_x) * TW, y0 = (tile_id / a.tiles_x) * G::TH;
+  const int band = blockIdx.x, bands = gridDim.x;   // one row band per workgroup, x-tiles walked in order (see dwconv_kernel)
+  const int y0_band = band * G::TH;
   const int j = blockIdx.y, b = blockIdx.z, h = a.hidden;
-  const int tx = threadIdx.x % G::TXN, ty = threadIdx.x / G::TXN;
-  const int oy = y0 + RPT * ty, ox = x0 + 4 * tx;
   const int64_t HW = (int64_t)a.H * a.W;
   const T* dgp = (const T*)a.in + ((int64_t)b * h + j) * HW;
   const T* y1p = (const T*)a.gy + ((int64_t)b * a.Cc + j) * HW;
@@ -361,11 +387,23 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
       for (int e = 0; e < 4; ++e) o[e] = gx + e < a.W ? ld1(plane + (int64_t)gy * a.W + gx + e) : 0.f;
     }
   };
+  float acc[2][KK + 1];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int i = 0; i <= KK; ++i) acc[pl][i] = 0.f;
+ for (int txi = 0; txi < a.tiles_x; ++txi) {
+  int y0 = y0_band;
+  DW_OPAQUE(y0);
+  const int tid_c = dw_tid(), tx = tid_c % G::TXN, ty = tid_c / G::TXN;
+  const int x0 = txi * TW, ox = x0 + 4 * tx, oy = y0 + RPT * ty;
+  if (txi) __syncthreads();
   {  // interior columns: all vector loads first, then the gate math and the LDS writes
     float vdg[S::NV][4], vy1[S::NV][4], vy2[S::NV][4], vx1[WANT_DW ? S::NV : 1][4], vx2[WANT_DW ? S::NV : 1][4];
+    const int tid = dw_tid();
 #pragma unroll
     for (int i = 0; i < S::NV; ++i) {
-      const int e = threadIdx.x + 256 * i;
+      const int e = tid + 256 * i;
       const int r = e / S::VPR, v = e - r * S::VPR;
       const int gy = y0 - P + r, gx = x0 + 4 * v;
       const bool in = e < G::LH * S::VPR && gy >= 0 && gy < a.H && gx < a.W;
@@ -382,7 +420,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
     }
 #pragma unroll
     for (int i = 0; i < S::NV; ++i) {
-      const int e = threadIdx.x + 256 * i;
+      const int e = tid + 256 * i;
       if (e < G::LH * S::VPR) {
         const int r = e / S::VPR, v = e - r * S::VPR;
         const int o = r * G::LW + P + 4 * v;
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
       }
     }
   }
-  for (int e = threadIdx.x; e < G::LH * 2 * P; e += 256) {  // halo columns
+  for (int e = dw_tid(); e < G::LH * 2 * P; e += 256) {  // halo columns
     const int r = e / (2 * P), hcol = e - r * (2 * P);
     const int c = hcol < P ? hcol : TW + hcol;
     const int gy = y0 - P + r, gx = x0 - P + c;
@@ -428,21 +466,17 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
       dw_store4<T>((T*)a.out + ((int64_t)b * a.Cc + j + h) * HW, a.H, a.W, oy + r, ox, o[r], vec_ok);
   }
   if (WANT_DW) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       const float* dyt = pl ? d2t : d1t;
       const float* xt = pl ? x2t : x1t;
-      float acc[KK + 1];
-#pragma unroll
-      for (int i = 0; i <= KK; ++i) acc[i] = 0.f;
       float d[RPT][4];
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           d[r][q] = dyt[(RPT * ty + r + P) * G::LW + 4 * tx + q + P];
-          acc[KK] += d[r][q];
+          acc[pl][KK] += d[r][q];
         }
 #pragma unroll
       for (int wr = 0; wr < G::WIN; ++wr) {
@@ -455,29 +489,35 @@ __global__ __launch_bounds__(256) void dwconv_gate_bwd_kernel(DwArgs a, const T*
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[ky * KS + kx] += d[r][q] * row[q + kx];
+            for (int q = 0; q < 4; ++q) acc[pl][ky * KS + kx] += d[r][q] * row[q + kx];
         }
       }
+    }
+  }
+ }  // x-tiles
+  if (WANT_DW) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
       for (int i = 0; i <= KK; ++i) {
-        const float sres = wave_sum(acc[i]);
+        const float sres = wave_sum(acc[pl][i]);
         if (lane == 0) red[wv][pl * (KK + 1) + i] = sres;
       }
-    }
     __syncthreads();
     if (threadIdx.x < 2 * (KK + 1)) {
       const int pl = threadIdx.x / (KK + 1), i = threadIdx.x - pl * (KK + 1);
       const int cc = pl ? j + h : j;
       const int k = threadIdx.x;
       const float sres = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-      float* prow = part + ((int64_t)b * tiles + tile_id) * ((int64_t)a.Cc * (KK + 1));
+      float* prow = part + ((int64_t)b * bands + band) * ((int64_t)a.Cc * (KK + 1));
       if (i < KK) prow[(int64_t)cc * KK + i] = sres;
       else prow[(int64_t)a.Cc * KK + cc] = sres;
     }
   }
 }
 
-struct DwTiling { int tw, rpt, th, tiles_x, tiles; };
+struct DwTiling { int tw, rpt, th, tiles_x, bands, tiles; };
 static DwTiling dw_tiling(int H, int W, int ks, int max_rpt = 4) {
   DwTiling t;
   t.tw = W >= 48 ? 64 : (W >= 24 ? 32 : 16);
@@ -485,7 +525,8 @@ static DwTiling dw_tiling(int H, int W, int ks, int max_rpt = 4) {
   t.rpt = (ks == 3 && H >= 2 * tyn) ? max_rpt : 1;  // tall tiles for 3x3 where the plane has the rows for them
   t.th = tyn * t.rpt;
   t.tiles_x = cdiv(W, t.tw);
-  t.tiles = t.tiles_x * cdiv(H, t.th);
+  t.bands = cdiv(H, t.th);  // one workgroup per row band; it loops over the band's tiles_x tiles
+  t.tiles = t.tiles_x * t.bands;
   return t;
 }
 
@@ -503,7 +544,7 @@ static int dw_launch(DwArgs a, int B, hipStream_t st) {
   const DwTiling tl = dw_tiling(a.H, a.W, KS, RMAX);
   a.tiles_x = tl.tiles_x;
   const int vec_ok = (a.W % 4 == 0) && aligned16(a.out) && aligned16(a.gate) && aligned16(a.in);
-  dim3 grid(tl.tiles, GATE ? a.hidden : a.Cc, B), block(256);
+  dim3 grid(tl.bands, GATE ? a.hidden : a.Cc, B), block(256);
   const double plane = (double)B * a.H * a.W * sizeof(T);
   const double chans = GATE ? (a.Cc + (a.out ? a.Cc : 0) + a.hidden) : 2.0 * a.Cc;
   ProfScope ps(st, GATE ? K_DW_GATE_FWD : K_DW_FWD, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
@@ -522,9 +563,9 @@ static int dw_bwd_launch(DwArgs dya, const void* xin, float* part, int B, bool w
                          hipStream_t st) {
   const DwTiling tl = dw_tiling(dya.H, dya.W, KS);
   dya.tiles_x = tl.tiles_x;
-  *rows_out = tl.tiles * B;
+  *rows_out = tl.bands * B;
   const int vec_ok = (dya.W % 4 == 0) && aligned16(dya.in) && aligned16(dya.gy) && aligned16(xin) && aligned16(dya.out);
-  dim3 grid(tl.tiles, dya.Cc, B), block(256);
+  dim3 grid(tl.bands, dya.Cc, B), block(256);
   const double plane = (double)B * dya.H * dya.W * sizeof(T);
   const double in_ch = MODE == IN_GATE_BWD ? dya.hidden + (double)dya.Cc : (double)dya.Cc;
   const int kid = want_dx ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_WGRAD;
@@ -552,9 +593,9 @@ template <typename T, int KS>
 static int dw_gate_bwd_launch(DwArgs a, const void* xin, float* part, int B, bool want_dw, int* rows_out, hipStream_t st) {
   const DwTiling tl = dw_tiling(a.H, a.W, KS, 2);
   a.tiles_x = tl.tiles_x;
-  *rows_out = tl.tiles * B;
+  *rows_out = tl.bands * B;
   const int vec_ok = (a.W % 4 == 0) && aligned16(a.in) && aligned16(a.gy) && aligned16(xin) && aligned16(a.out);
-  dim3 grid(tl.tiles, a.hidden, B), block(256);
+  dim3 grid(tl.bands, a.hidden, B), block(256);
   const double plane = (double)B * a.H * a.W * sizeof(T);
   ProfScope ps(st, a.out ? K_DW_GATE_BWD_DATA : K_DW_WGRAD,
                (a.hidden + (double)a.Cc + (want_dw ? a.Cc : 0) + (a.out ? a.Cc : 0)) * plane,
@@ -629,7 +670,7 @@ extern "C" size_t mi_dwconv_bwd_workspace(int B, int C, int H, int W, int ks) {
   if (H <= 0 || W <= 0 || C <= 0 || B <= 0) return 0;
   const DwTiling tl = dw_tiling(H, W, ks, 2);  // the gate backward uses the smaller (2 rows/thread) tiles: upper bound
   const size_t cols = (size_t)C * (ks * ks + 1);
-  return align_up(((size_t)tl.tiles * B + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
+  return align_up(((size_t)tl.bands * B + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
 }
 
 static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, const float* w, void* dx, float* dwg,
