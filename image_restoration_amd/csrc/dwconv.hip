@@ -8,21 +8,11 @@
 // instead of 2 KB: these kernels are HBM/latency bound and MI355X wants >= 40 KB in flight per CU).
 // Backward computes dx AND the weight/bias gradient partials in ONE pass over (dy, x): the dy tile is staged
 // once and used for both.
-#include "common.h"
+#include "internal.h"
+#include <algorithm>
+#include <type_traits>
 
 namespace mi {
-
-enum { IN_PLAIN = 0, IN_GATE_BWD = 1 };
-
-struct DwArgs {
-  const void* in;     // plain: x / dy  [B,Cc,H,W]
-  const void* gy;     // gate-bwd: conv outputs y [B,2h,H,W] (in = dg [B,h,H,W])
-  const float* w;     // [Cc, KS*KS]
-  const float* bias;  // [Cc] or null
-  void* out;          // [B,Cc,H,W] (may be null in gate fwd)
-  void* gate;         // gate fwd: g [B,h,H,W]
-  int Cc, H, W, hidden, tiles_x;
-};
 
 template <typename T, int MODE>
 __device__ __forceinline__ float dw_fetch(const DwArgs& a, int b, int cc, int y, int x) {
@@ -548,6 +538,8 @@ static int dw_launch(DwArgs a, int B, hipStream_t st) {
   const double plane = (double)B * a.H * a.W * sizeof(T);
   const double chans = GATE ? (a.Cc + (a.out ? a.Cc : 0) + a.hidden) : 2.0 * a.Cc;
   ProfScope ps(st, GATE ? K_DW_GATE_FWD : K_DW_FWD, chans * plane, 2.0 * KS * KS * a.Cc * (double)B * a.H * a.W);
+  if (KS == 3 && vec_ok && dws_eligible(a.H, a.W, KS))   // 3x3 on power-of-two rows: register-streaming kernels (dwstream.hip)
+    return dws_fwd(a, B, GATE, false, std::is_same<T, float>::value ? MI_F32 : MI_BF16, st);
 #define DW_FWD_LAUNCH(TWV, RPTV) \
   hipLaunchKernelGGL((dwconv_kernel<T, KS, TWV, RPTV, GATE>), grid, block, 0, st, a, vec_ok)
   if (tl.tw == 64) { if (tl.rpt > 1) DW_FWD_LAUNCH(64, RMAX); else DW_FWD_LAUNCH(64, 1); }
@@ -571,6 +563,11 @@ static int dw_bwd_launch(DwArgs dya, const void* xin, float* part, int B, bool w
   const int kid = want_dx ? (MODE == IN_GATE_BWD ? K_DW_GATE_BWD_DATA : K_DW_BWD_DATA) : K_DW_WGRAD;
   ProfScope ps(st, kid, (in_ch + (want_dw ? dya.Cc : 0) + (want_dx ? dya.Cc : 0)) * plane,
                ((want_dx ? 2.0 : 0.0) + (want_dw ? 2.0 : 0.0)) * KS * KS * dya.Cc * (double)B * dya.H * dya.W);
+  if (KS == 3 && MODE == IN_PLAIN && vec_ok && dws_eligible(dya.H, dya.W, KS)) {
+    const int dt = std::is_same<T, float>::value ? MI_F32 : MI_BF16;
+    if (want_dw) return dws_bwd(dya, xin, part, B, want_dx, rows_out, dt, st);
+    return dws_fwd(dya, B, false, true, dt, st);
+  }
 #define DW_BWD_LAUNCH(TWV, RPTV)                                                                                          \
   do {                                                                                                                    \
     if (want_dx && want_dw)                                                                                               \
@@ -600,6 +597,8 @@ static int dw_gate_bwd_launch(DwArgs a, const void* xin, float* part, int B, boo
   ProfScope ps(st, a.out ? K_DW_GATE_BWD_DATA : K_DW_WGRAD,
                (a.hidden + (double)a.Cc + (want_dw ? a.Cc : 0) + (a.out ? a.Cc : 0)) * plane,
                ((a.out ? 2.0 : 0.0) + (want_dw ? 2.0 : 0.0)) * KS * KS * a.Cc * (double)B * a.H * a.W);
+  if (KS == 3 && vec_ok && dws_eligible(a.H, a.W, KS))
+    return dws_gate_bwd(a, xin, part, B, want_dw, rows_out, std::is_same<T, float>::value ? MI_F32 : MI_BF16, st);
 #define DW_GB_LAUNCH(TWV, RPTV)                                                                                       \
   do {                                                                                                                \
     if (want_dw)                                                                                                      \
@@ -670,7 +669,12 @@ extern "C" size_t mi_dwconv_bwd_workspace(int B, int C, int H, int W, int ks) {
   if (H <= 0 || W <= 0 || C <= 0 || B <= 0) return 0;
   const DwTiling tl = dw_tiling(H, W, ks, 2);  // the gate backward uses the smaller (2 rows/thread) tiles: upper bound
   const size_t cols = (size_t)C * (ks * ks + 1);
-  return align_up(((size_t)tl.bands * B + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
+  size_t rows = (size_t)tl.bands * B;
+  if (dws_eligible(H, W, ks)) {  // the streaming kernels write one partial row per (image, band): cover both plans
+    rows = std::max(rows, (size_t)dws_partial_rows(B, H, W, (int64_t)B * C));
+    rows = std::max(rows, (size_t)dws_partial_rows(B, H, W, (int64_t)B * C / 2));
+  }
+  return align_up((rows + 2 * REDUCE_GROUPS) * cols * sizeof(float), 256);
 }
 
 static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, const float* w, void* dx, float* dwg,

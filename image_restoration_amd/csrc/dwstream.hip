@@ -1,0 +1,451 @@
+// Register-streaming depthwise 3x3 (Restormer.py:84,106 and their backward), the form every Restormer / MoCE-IR plane
+// at 256^2 training takes (rows of 16..256 pixels).
+//
+// The LDS-tiled kernels in dwconv.hip run load -> barrier -> compute -> store phases, and with 3-5 workgroups per CU
+// the memory pipe idles while a workgroup computes (measured: 70 % of wave time in waits at 2.3-3.3 TB/s, and removing
+// the halo-column reads entirely changed nothing).  Here a WAVE owns a band of rows of one plane and streams down it:
+//   * a lane owns 4 consecutive pixels of the row; 64 lanes cover a 256-pixel row (narrower rows: 64/LPR bands side by
+//     side in one wave), so every load/store instruction moves whole 128-byte lines and nothing is fetched twice
+//     except the two halo rows of a band;
+//   * the left/right neighbours come from the adjacent lanes with one DPP wave shift each (v_mov_b32_dpp wave_shr:1 /
+//     wave_shl:1) - no LDS, no barrier, waves never wait for each other;
+//   * the rows of the next PF steps are already in flight (raw, unconverted) while the current ones are computed, so
+//     each wave keeps PF rows x planes of loads outstanding and 8 waves/SIMD keep the HBM queues full.
+// Backward forms dx with the flipped taps from the same dy window and accumulates the weight gradient as
+//   dW[ky][kx] += x[y][x'] * dy[y-ky+1][x'-kx+1]
+// (the dy window is needed anyway; x is then only needed at the centre row, without neighbours).
+#include "internal.h"
+
+namespace mi {
+namespace {
+
+template <typename T> struct Raw;
+template <> struct Raw<bf16> {
+  using V = u32x2;
+  static __device__ __forceinline__ V zero() { V z = {0u, 0u}; return z; }
+  static __device__ __forceinline__ void expand(const V& t, float* o) {
+    o[0] = bf16_bits_to_f32(t[0] & 0xffffu); o[1] = bf16_bits_to_f32(t[0] >> 16);
+    o[2] = bf16_bits_to_f32(t[1] & 0xffffu); o[3] = bf16_bits_to_f32(t[1] >> 16);
+  }
+};
+template <> struct Raw<float> {
+  using V = f32x4;
+  static __device__ __forceinline__ V zero() { V z = {0.f, 0.f, 0.f, 0.f}; return z; }
+  static __device__ __forceinline__ void expand(const V& t, float* o) { o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// r[0] = pixel left of the lane's 4, r[1..4] = own, r[5] = right; zero outside the row.
+__device__ __forceinline__ void window_row(const float* v, bool first, bool last, float* r) {
+  const float l = dpp_mov<0x138>(v[3]);  // wave_shr:1  lane i <- lane i-1
+  const float g = dpp_mov<0x130>(v[0]);  // wave_shl:1  lane i <- lane i+1
+  r[0] = first ? 0.f : l;
+  r[1] = v[0]; r[2] = v[1]; r[3] = v[2]; r[4] = v[3];
+  r[5] = last ? 0.f : g;
+}
+// out[j] = b + sum_{ky,kx} w[ky*3+kx] * r_ky[j+kx]
+__device__ __forceinline__ void stencil(const float* w, float b, const float* r0, const float* r1, const float* r2, float* o) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s = b;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[kx] * r0[j + kx];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[3 + kx] * r1[j + kx];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[6 + kx] * r2[j + kx];
+    o[j] = s;
+  }
+}
+// acc[ky*3+kx] += sum_j x[j] * d_(y-ky+1)[j-kx+1]   (window index j-kx+2; rows: ky=0 -> below, 1 -> centre, 2 -> above)
+__device__ __forceinline__ void wgrad_row(const float* x, const float* up, const float* mid, const float* dn, float* acc) {
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[kx] += x[j] * dn[j - kx + 2];
+      acc[3 + kx] += x[j] * mid[j - kx + 2];
+      acc[6 + kx] += x[j] * up[j - kx + 2];
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[9] += mid[j + 1];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v) { Vec<T, 4>::st(p, v); }
+__device__ __forceinline__ void copy6(float* d, const float* s) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d[i] = s[i];
+}
+
+// Geometry shared by the three kernels: which band of which plane this lane group works on.
+template <int LPR> struct Unit {
+  int lx, plane, band, y0;
+  bool active;
+  __device__ __forceinline__ Unit(int planes, int nb, int band_rows) {
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lx = lane % LPR;
+    const int64_t u = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR;
+    plane = (int)(u / nb);
+    band = (int)(u - (int64_t)plane * nb);
+    active = plane < planes;
+    y0 = band * band_rows;
+  }
+};
+// sum over the LPR lanes of a group (xor butterfly); every lane of the group ends with the total
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+constexpr int PF = 4;  // rows in flight per plane (forward / plain backward)
+
+// ---- forward (and backward-data alone, with flip = 1) -----------------------------------------------------------------
+template <typename T, bool GATE, int LPR>
+__global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int nb, int band_rows, int flip) {
+  using R = Raw<T>;
+  using RV = typename R::V;
+  const Unit<LPR> u(planes, nb, band_rows);
+  const int CH = GATE ? a.hidden : a.Cc;
+  const int b = u.active ? u.plane / CH : 0, cc = u.active ? u.plane - b * CH : 0;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int x = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const T* in1 = (const T*)a.in + ((int64_t)b * a.Cc + cc) * HW + x;
+  const T* in2 = in1 + (int64_t)a.hidden * HW;
+  float w1[9], w2[GATE ? 9 : 1], b1 = 0.f, b2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    w1[i] = a.w[(int64_t)cc * 9 + (flip ? 8 - i : i)];
+    if (GATE) w2[i] = a.w[(int64_t)(cc + a.hidden) * 9 + i];
+  }
+  if (a.bias) { b1 = a.bias[cc]; if (GATE) b2 = a.bias[cc + a.hidden]; }
+  const int yend = min(u.y0 + band_rows, a.H);      // rows [y0, yend) are this unit's outputs
+  auto ld = [&](const T* base, int y) -> RV {
+    return (u.active && y >= 0 && y <= yend && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+  };
+  float p0[6], p1[6], p2[6], q0[GATE ? 6 : 1], q1[GATE ? 6 : 1], q2[GATE ? 6 : 1], v[4];
+  RV c1[PF], c2[GATE ? PF : 1];
+  {
+    const RV ra = ld(in1, u.y0 - 1), rb = ld(in1, u.y0);
+    RV sa = R::zero(), sb = R::zero();
+    if (GATE) { sa = ld(in2, u.y0 - 1); sb = ld(in2, u.y0); }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { c1[i] = ld(in1, u.y0 + 1 + i); if (GATE) c2[i] = ld(in2, u.y0 + 1 + i); }
+    R::expand(ra, v); window_row(v, first, last, p0);
+    R::expand(rb, v); window_row(v, first, last, p1);
+    if (GATE) {
+      R::expand(sa, v); window_row(v, first, last, q0);
+      R::expand(sb, v); window_row(v, first, last, q1);
+    }
+  }
+  T* out1 = a.out ? (T*)a.out + ((int64_t)b * a.Cc + cc) * HW + x : nullptr;
+  T* out2 = out1 ? out1 + (int64_t)a.hidden * HW : nullptr;
+  T* outg = GATE ? (T*)a.gate + ((int64_t)b * a.hidden + cc) * HW + x : nullptr;
+  for (int yy = 0; yy < band_rows; yy += PF) {
+    RV n1[PF], n2[GATE ? PF : 1];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      n1[i] = ld(in1, u.y0 + yy + PF + 1 + i);
+      if (GATE) n2[i] = ld(in2, u.y0 + yy + PF + 1 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int y = u.y0 + yy + i;
+      const bool st = u.active && y < yend;
+      float o1[4];
+      R::expand(c1[i], v); window_row(v, first, last, p2);
+      stencil(w1, b1, p0, p1, p2, o1);
+      if (!GATE) {
+        if (st) store4(out1 + (int64_t)y * a.W, o1);
+      } else {
+        float o2[4], g[4];
+        R::expand(c2[i], v); window_row(v, first, last, q2);
+        stencil(w2, b2, q0, q1, q2, o2);
+        if (out1) {
+          if (st) { store4(out1 + (int64_t)y * a.W, o1); store4(out2 + (int64_t)y * a.W, o2); }
+          // the gate is evaluated on the values as stored (what backward re-reads)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { o1[j] = to_f32(Cvt<T>::from(o1[j])); o2[j] = to_f32(Cvt<T>::from(o2[j])); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gelu_erf(o1[j]) * o2[j];
+        if (st) store4(outg + (int64_t)y * a.W, g);
+        copy6(q0, q1); copy6(q1, q2);
+      }
+      copy6(p0, p1); copy6(p1, p2);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { c1[i] = n1[i]; if (GATE) c2[i] = n2[i]; }
+  }
+}
+
+// ---- plain backward: dx (optional) + dW/db partials ---------------------------------------------------------------------
+template <typename T, int LPR, bool WANT_DX>
+__global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
+                                                      int planes, int nb, int band_rows) {
+  using R = Raw<T>;
+  using RV = typename R::V;
+  const Unit<LPR> u(planes, nb, band_rows);
+  const int b = u.active ? u.plane / a.Cc : 0, cc = u.active ? u.plane - b * a.Cc : 0;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int x = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const T* dyp = (const T*)a.in + ((int64_t)b * a.Cc + cc) * HW + x;
+  const T* xp = xin + ((int64_t)b * a.Cc + cc) * HW + x;
+  float wf[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) wf[i] = a.w[(int64_t)cc * 9 + 8 - i];
+  const int yend = min(u.y0 + band_rows, a.H);
+  auto ld = [&](const T* base, int y, int ymax) -> RV {
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+  };
+  float p0[6], p1[6], p2[6], v[4], acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  RV cd[PF], cx[PF];
+  {
+    const RV ra = ld(dyp, u.y0 - 1, yend), rb = ld(dyp, u.y0, yend);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { cd[i] = ld(dyp, u.y0 + 1 + i, yend); cx[i] = ld(xp, u.y0 + i, yend - 1); }
+    R::expand(ra, v); window_row(v, first, last, p0);
+    R::expand(rb, v); window_row(v, first, last, p1);
+  }
+  T* outp = WANT_DX ? (T*)a.out + ((int64_t)b * a.Cc + cc) * HW + x : nullptr;
+  for (int yy = 0; yy < band_rows; yy += PF) {
+    RV nd[PF], nx[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      nd[i] = ld(dyp, u.y0 + yy + PF + 1 + i, yend);
+      nx[i] = ld(xp, u.y0 + yy + PF + i, yend - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int y = u.y0 + yy + i;
+      const bool st = u.active && y < yend;
+      R::expand(cd[i], v); window_row(v, first, last, p2);
+      if (WANT_DX) {
+        float o[4];
+        stencil(wf, 0.f, p0, p1, p2, o);
+        if (st) store4(outp + (int64_t)y * a.W, o);
+      }
+      float xr[4];
+      R::expand(cx[i], xr);                 // zero beyond the band: those rows belong to the next unit
+      if (y < yend) wgrad_row(xr, p0, p1, p2, acc);
+      copy6(p0, p1); copy6(p1, p2);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = group_sum<LPR>(acc[i]);
+  if (u.active && u.lx == 0) {
+    float* prow = part + ((int64_t)b * nb + u.band) * ((int64_t)a.Cc * 10);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) prow[(int64_t)cc * 9 + i] = acc[i];
+    prow[(int64_t)a.Cc * 9 + cc] = acc[9];
+  }
+}
+
+// ---- GDFN gate backward (Restormer.py:90-91 backwards), channel pair (j, j+h) per unit -----------------------------------
+//   d1 = dg * y2 * gelu'(y1),  d2 = dg * gelu(y1);  dx_j = conv^T(d1, w_j), dx_{j+h} = conv^T(d2, w_{j+h});  dW/db of both.
+constexpr int PFG = 2;
+template <typename T, int LPR, bool WANT_DW>
+__global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
+                                                           int planes, int nb, int band_rows) {
+  using R = Raw<T>;
+  using RV = typename R::V;
+  const Unit<LPR> u(planes, nb, band_rows);
+  const int h = a.hidden;
+  const int b = u.active ? u.plane / h : 0, j = u.active ? u.plane - b * h : 0;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int x = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const T* dgp = (const T*)a.in + ((int64_t)b * h + j) * HW + x;
+  const T* y1p = (const T*)a.gy + ((int64_t)b * a.Cc + j) * HW + x;
+  const T* y2p = y1p + (int64_t)h * HW;
+  const T* x1p = xin + ((int64_t)b * a.Cc + j) * HW + x;
+  const T* x2p = x1p + (int64_t)h * HW;
+  float w1[9], w2[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { w1[i] = a.w[(int64_t)j * 9 + 8 - i]; w2[i] = a.w[(int64_t)(j + h) * 9 + 8 - i]; }
+  const int yend = min(u.y0 + band_rows, a.H);
+  auto ld = [&](const T* base, int y, int ymax) -> RV {
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+  };
+  // one row of (dg, y1, y2) -> window rows of d1 and d2
+  auto gate_row = [&](const RV& rdg, const RV& ry1, const RV& ry2, float* r1, float* r2) {
+    float dg[4], y1[4], y2[4], d1[4], d2[4];
+    R::expand(rdg, dg); R::expand(ry1, y1); R::expand(ry2, y2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float cdf, pdf;
+      gelu_parts(y1[q], cdf, pdf);
+      d1[q] = dg[q] * y2[q] * (cdf + y1[q] * pdf);
+      d2[q] = dg[q] * y1[q] * cdf;
+    }
+    window_row(d1, first, last, r1);
+    window_row(d2, first, last, r2);
+  };
+  float p0[6], p1[6], p2[6], q0[6], q1[6], q2[6];
+  float acc1[WANT_DW ? 10 : 1], acc2[WANT_DW ? 10 : 1];
+  if (WANT_DW) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
+  }
+  RV cg[PFG], ca[PFG], cb[PFG], cx1[WANT_DW ? PFG : 1], cx2[WANT_DW ? PFG : 1];
+  {
+    const RV g0 = ld(dgp, u.y0 - 1, yend), a0 = ld(y1p, u.y0 - 1, yend), b0 = ld(y2p, u.y0 - 1, yend);
+    const RV g1 = ld(dgp, u.y0, yend), a1 = ld(y1p, u.y0, yend), b1 = ld(y2p, u.y0, yend);
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      cg[i] = ld(dgp, u.y0 + 1 + i, yend); ca[i] = ld(y1p, u.y0 + 1 + i, yend); cb[i] = ld(y2p, u.y0 + 1 + i, yend);
+      if (WANT_DW) { cx1[i] = ld(x1p, u.y0 + i, yend - 1); cx2[i] = ld(x2p, u.y0 + i, yend - 1); }
+    }
+    gate_row(g0, a0, b0, p0, q0);
+    gate_row(g1, a1, b1, p1, q1);
+  }
+  T* o1p = a.out ? (T*)a.out + ((int64_t)b * a.Cc + j) * HW + x : nullptr;
+  T* o2p = o1p ? o1p + (int64_t)h * HW : nullptr;
+  for (int yy = 0; yy < band_rows; yy += PFG) {
+    RV ng[PFG], na[PFG], nbb[PFG], nx1[WANT_DW ? PFG : 1], nx2[WANT_DW ? PFG : 1];
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      const int yn = u.y0 + yy + PFG + 1 + i;
+      ng[i] = ld(dgp, yn, yend); na[i] = ld(y1p, yn, yend); nbb[i] = ld(y2p, yn, yend);
+      if (WANT_DW) { nx1[i] = ld(x1p, yn - 1, yend - 1); nx2[i] = ld(x2p, yn - 1, yend - 1); }
+    }
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      const int y = u.y0 + yy + i;
+      const bool st = u.active && y < yend;
+      gate_row(cg[i], ca[i], cb[i], p2, q2);
+      if (o1p) {
+        float o[4];
+        stencil(w1, 0.f, p0, p1, p2, o);
+        if (st) store4(o1p + (int64_t)y * a.W, o);
+        stencil(w2, 0.f, q0, q1, q2, o);
+        if (st) store4(o2p + (int64_t)y * a.W, o);
+      }
+      if (WANT_DW) {
+        float xr[4];
+        R::expand(cx1[i], xr);
+        if (y < yend) wgrad_row(xr, p0, p1, p2, acc1);
+        R::expand(cx2[i], xr);
+        if (y < yend) wgrad_row(xr, q0, q1, q2, acc2);
+      }
+      copy6(p0, p1); copy6(p1, p2); copy6(q0, q1); copy6(q1, q2);
+    }
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      cg[i] = ng[i]; ca[i] = na[i]; cb[i] = nbb[i];
+      if (WANT_DW) { cx1[i] = nx1[i]; cx2[i] = nx2[i]; }
+    }
+  }
+  if (WANT_DW) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { acc1[i] = group_sum<LPR>(acc1[i]); acc2[i] = group_sum<LPR>(acc2[i]); }
+    if (u.active && u.lx == 0) {
+      float* prow = part + ((int64_t)b * nb + u.band) * ((int64_t)a.Cc * 10);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { prow[(int64_t)j * 9 + i] = acc1[i]; prow[(int64_t)(j + h) * 9 + i] = acc2[i]; }
+      prow[(int64_t)a.Cc * 9 + j] = acc1[9];
+      prow[(int64_t)a.Cc * 9 + j + h] = acc2[9];
+    }
+  }
+}
+
+// rows per band: tall bands amortise the two halo rows; short ones keep >= ~8 waves per SIMD on small launches
+static int pick_band(int H, int64_t planes, int lpr) {
+  const int G = 64 / lpr;
+  for (int band : {32, 16}) {
+    const int64_t waves = planes * cdiv(H, band) / G;
+    if (waves >= 8192) return band;
+  }
+  return 8;
+}
+struct Plan { int band, nb; unsigned blocks; };
+static Plan make_plan(int H, int W, int64_t planes) {
+  const int lpr = W / 4, G = 64 / lpr;
+  Plan p;
+  p.band = pick_band(H, planes, lpr);
+  p.nb = cdiv(H, p.band);
+  const int64_t units = planes * p.nb;
+  p.blocks = (unsigned)((units + 4 * G - 1) / (4 * G));
+  return p;
+}
+
+#define DWS_LPR_SWITCH(W_, CALL)                     \
+  switch ((W_) / 4) {                                \
+    case 64: { constexpr int LPR = 64; CALL; } break; \
+    case 32: { constexpr int LPR = 32; CALL; } break; \
+    case 16: { constexpr int LPR = 16; CALL; } break; \
+    case 8: { constexpr int LPR = 8; CALL; } break;   \
+    default: { constexpr int LPR = 4; CALL; } break;  \
+  }
+
+}  // namespace
+
+bool dws_eligible(int H, int W, int ks) {
+  if (ks != 3 || H < 1) return false;
+  if (getenv("MI_DW_LDS")) return false;  // A/B switch: force the LDS-tiled kernels
+  return W == 16 || W == 32 || W == 64 || W == 128 || W == 256;
+}
+
+int dws_partial_rows(int B, int H, int W, int64_t planes) { return make_plan(H, W, planes).nb * B; }
+
+int dws_fwd(const DwArgs& a, int B, bool gate, bool flip, int dtype, hipStream_t st) {
+  const int64_t planes = (int64_t)B * (gate ? a.hidden : a.Cc);
+  const Plan p = make_plan(a.H, a.W, planes);
+  dim3 grid(p.blocks), block(256);
+#define DWS_FWD(T_)                                                                                                      \
+  DWS_LPR_SWITCH(a.W, {                                                                                                  \
+    if (gate) hipLaunchKernelGGL((dws_fwd_kernel<T_, true, LPR>), grid, block, 0, st, a, (int)planes, p.nb, p.band, 0);  \
+    else hipLaunchKernelGGL((dws_fwd_kernel<T_, false, LPR>), grid, block, 0, st, a, (int)planes, p.nb, p.band, flip ? 1 : 0); \
+  })
+  if (dtype == MI_F32) { DWS_FWD(float); } else { DWS_FWD(bf16); }
+#undef DWS_FWD
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int dws_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want_dx, int* rows_out, int dtype, hipStream_t st) {
+  const int64_t planes = (int64_t)B * a.Cc;
+  const Plan p = make_plan(a.H, a.W, planes);
+  *rows_out = p.nb * B;
+  dim3 grid(p.blocks), block(256);
+#define DWS_BWD(T_)                                                                                              \
+  DWS_LPR_SWITCH(a.W, {                                                                                          \
+    if (want_dx) hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, true>), grid, block, 0, st, a, (const T_*)xin, part, \
+                                    (int)planes, p.nb, p.band);                                                  \
+    else hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
+                            (int)planes, p.nb, p.band);                                                          \
+  })
+  if (dtype == MI_F32) { DWS_BWD(float); } else { DWS_BWD(bf16); }
+#undef DWS_BWD
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want_dw, int* rows_out, int dtype,
+                 hipStream_t st) {
+  const int64_t planes = (int64_t)B * a.hidden;
+  const Plan p = make_plan(a.H, a.W, planes);
+  *rows_out = p.nb * B;
+  dim3 grid(p.blocks), block(256);
+#define DWS_GB(T_)                                                                                                    \
+  DWS_LPR_SWITCH(a.W, {                                                                                               \
+    if (want_dw) hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, true>), grid, block, 0, st, a, (const T_*)xin, part, \
+                                    (int)planes, p.nb, p.band);                                                       \
+    else hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
+                            (int)planes, p.nb, p.band);                                                               \
+  })
+  if (dtype == MI_F32) { DWS_GB(float); } else { DWS_GB(bf16); }
+#undef DWS_GB
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+}  // namespace mi

@@ -21,4 +21,23 @@ int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const
 size_t attn_bwd_scratch_floats(int B, int C, int heads);
 size_t chan_sum_workspace(int C, int64_t N);
 int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtype, int accumulate, void* ws, hipStream_t st);
+
+// ---- depthwise convolution (dwconv.hip: LDS-tiled k x k; dwstream.hip: register-streaming 3x3) ----
+enum { IN_PLAIN = 0, IN_GATE_BWD = 1 };
+struct DwArgs {
+  const void* in;     // plain: x / dy  [B,Cc,H,W]
+  const void* gy;     // gate-bwd: conv outputs y [B,2h,H,W] (in = dg [B,h,H,W])
+  const float* w;     // [Cc, KS*KS]
+  const float* bias;  // [Cc] or null
+  void* out;          // [B,Cc,H,W] (may be null in gate fwd)
+  void* gate;         // gate fwd: g [B,h,H,W]
+  int Cc, H, W, hidden, tiles_x;
+};
+// Streaming 3x3 path: usable when the row is 16..256 pixels, a power of two, and every plane base is 16-byte aligned.
+bool dws_eligible(int H, int W, int ks);
+int dws_partial_rows(int B, int H, int W, int64_t planes);  // rows of weight-gradient partials the backward kernels write
+int dws_fwd(const DwArgs& a, int B, bool gate, bool flip, int dtype, hipStream_t st);
+int dws_bwd(const DwArgs& dya, const void* xin, float* part, int B, bool want_dx, int* rows_out, int dtype, hipStream_t st);
+int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want_dw, int* rows_out, int dtype,
+                 hipStream_t st);
 }  // namespace mi

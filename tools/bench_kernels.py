@@ -72,6 +72,9 @@ def bench_dw():
         if C % 2 == 0:
             us = timeit(lambda: ops.dwconv_gate_fwd(x, w, None))
             print(f"dw_gate_fwd C={C} {H}x{W}: {us:8.1f} us {2.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+            dg = x[:, : C // 2].contiguous()
+            us = timeit(lambda: ops.dwconv_gate_bwd(dg, x, x, w, False))
+            print(f"dw_gate_bwd C={C} {H}x{W}: {us:8.1f} us {3.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
 
 
 def bench_gram():
