@@ -79,7 +79,7 @@ __device__ __forceinline__ void copy6(float* d, const float* s) {
 }
 
 // Geometry shared by the three kernels: which band of which plane this lane group works on.
-template <int LPR> struct Unit {
+template <int LPR, bool UNI> struct Unit {
   int lx, plane, band, y0;
   bool active;
   __device__ __forceinline__ Unit(int planes, int nb, int band_rows) {
@@ -89,6 +89,10 @@ template <int LPR> struct Unit {
     const int64_t u = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR;
     plane = (int)(u / nb);
     band = (int)(u - (int64_t)plane * nb);
+    // UNI: every lane group of the wave works on the same plane (nb is a multiple of the groups per wave): say so,
+    // and the tap weights, bias and plane bases live in SGPRs instead of 20-40 VGPRs
+    if (UNI) plane = __builtin_amdgcn_readfirstlane(plane);
+    if (LPR == 64) band = __builtin_amdgcn_readfirstlane(band);
     active = plane < planes;
     y0 = band * band_rows;
   }
@@ -103,11 +107,11 @@ template <int LPR> __device__ __forceinline__ float group_sum(float v) {
 constexpr int PF = 4;  // rows in flight per plane (forward / plain backward)
 
 // ---- forward (and backward-data alone, with flip = 1) -----------------------------------------------------------------
-template <typename T, bool GATE, int LPR>
+template <typename T, bool GATE, int LPR, bool UNI>
 __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int nb, int band_rows, int flip) {
   using R = Raw<T>;
   using RV = typename R::V;
-  const Unit<LPR> u(planes, nb, band_rows);
+  const Unit<LPR, UNI> u(planes, nb, band_rows);
   const int CH = GATE ? a.hidden : a.Cc;
   const int b = u.active ? u.plane / CH : 0, cc = u.active ? u.plane - b * CH : 0;
   const int64_t HW = (int64_t)a.H * a.W;
@@ -145,24 +149,22 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
   T* out2 = out1 ? out1 + (int64_t)a.hidden * HW : nullptr;
   T* outg = GATE ? (T*)a.gate + ((int64_t)b * a.hidden + cc) * HW + x : nullptr;
   for (int yy = 0; yy < band_rows; yy += PF) {
-    RV n1[PF], n2[GATE ? PF : 1];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      n1[i] = ld(in1, u.y0 + yy + PF + 1 + i);
-      if (GATE) n2[i] = ld(in2, u.y0 + yy + PF + 1 + i);
-    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int y = u.y0 + yy + i;
       const bool st = u.active && y < yend;
       float o1[4];
-      R::expand(c1[i], v); window_row(v, first, last, p2);
+      R::expand(c1[i], v);
+      c1[i] = ld(in1, y + PF + 1);          // the slot is free again: keep PF rows of every plane in flight
+      window_row(v, first, last, p2);
       stencil(w1, b1, p0, p1, p2, o1);
       if (!GATE) {
         if (st) store4(out1 + (int64_t)y * a.W, o1);
       } else {
         float o2[4], g[4];
-        R::expand(c2[i], v); window_row(v, first, last, q2);
+        R::expand(c2[i], v);
+        c2[i] = ld(in2, y + PF + 1);
+        window_row(v, first, last, q2);
         stencil(w2, b2, q0, q1, q2, o2);
         if (out1) {
           if (st) { store4(out1 + (int64_t)y * a.W, o1); store4(out2 + (int64_t)y * a.W, o2); }
@@ -177,18 +179,16 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
       }
       copy6(p0, p1); copy6(p1, p2);
     }
-#pragma unroll
-    for (int i = 0; i < PF; ++i) { c1[i] = n1[i]; if (GATE) c2[i] = n2[i]; }
   }
 }
 
 // ---- plain backward: dx (optional) + dW/db partials ---------------------------------------------------------------------
-template <typename T, int LPR, bool WANT_DX>
+template <typename T, int LPR, bool UNI, bool WANT_DX>
 __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
                                                       int planes, int nb, int band_rows) {
   using R = Raw<T>;
   using RV = typename R::V;
-  const Unit<LPR> u(planes, nb, band_rows);
+  const Unit<LPR, UNI> u(planes, nb, band_rows);
   const int b = u.active ? u.plane / a.Cc : 0, cc = u.active ? u.plane - b * a.Cc : 0;
   const int64_t HW = (int64_t)a.H * a.W;
   const int x = 4 * u.lx;
@@ -215,17 +215,13 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
   }
   T* outp = WANT_DX ? (T*)a.out + ((int64_t)b * a.Cc + cc) * HW + x : nullptr;
   for (int yy = 0; yy < band_rows; yy += PF) {
-    RV nd[PF], nx[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      nd[i] = ld(dyp, u.y0 + yy + PF + 1 + i, yend);
-      nx[i] = ld(xp, u.y0 + yy + PF + i, yend - 1);
-    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int y = u.y0 + yy + i;
       const bool st = u.active && y < yend;
-      R::expand(cd[i], v); window_row(v, first, last, p2);
+      R::expand(cd[i], v);
+      cd[i] = ld(dyp, y + PF + 1, yend);
+      window_row(v, first, last, p2);
       if (WANT_DX) {
         float o[4];
         stencil(wf, 0.f, p0, p1, p2, o);
@@ -233,11 +229,10 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
       }
       float xr[4];
       R::expand(cx[i], xr);                 // zero beyond the band: those rows belong to the next unit
+      cx[i] = ld(xp, y + PF, yend - 1);
       if (y < yend) wgrad_row(xr, p0, p1, p2, acc);
       copy6(p0, p1); copy6(p1, p2);
     }
-#pragma unroll
-    for (int i = 0; i < PF; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; }
   }
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = group_sum<LPR>(acc[i]);
@@ -252,12 +247,12 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
 // ---- GDFN gate backward (Restormer.py:90-91 backwards), channel pair (j, j+h) per unit -----------------------------------
 //   d1 = dg * y2 * gelu'(y1),  d2 = dg * gelu(y1);  dx_j = conv^T(d1, w_j), dx_{j+h} = conv^T(d2, w_{j+h});  dW/db of both.
 constexpr int PFG = 2;
-template <typename T, int LPR, bool WANT_DW>
+template <typename T, int LPR, bool UNI, bool WANT_DW>
 __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __restrict__ xin, float* __restrict__ part,
                                                            int planes, int nb, int band_rows) {
   using R = Raw<T>;
   using RV = typename R::V;
-  const Unit<LPR> u(planes, nb, band_rows);
+  const Unit<LPR, UNI> u(planes, nb, band_rows);
   const int h = a.hidden;
   const int b = u.active ? u.plane / h : 0, j = u.active ? u.plane - b * h : 0;
   const int64_t HW = (int64_t)a.H * a.W;
@@ -310,18 +305,12 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
   T* o1p = a.out ? (T*)a.out + ((int64_t)b * a.Cc + j) * HW + x : nullptr;
   T* o2p = o1p ? o1p + (int64_t)h * HW : nullptr;
   for (int yy = 0; yy < band_rows; yy += PFG) {
-    RV ng[PFG], na[PFG], nbb[PFG], nx1[WANT_DW ? PFG : 1], nx2[WANT_DW ? PFG : 1];
-#pragma unroll
-    for (int i = 0; i < PFG; ++i) {
-      const int yn = u.y0 + yy + PFG + 1 + i;
-      ng[i] = ld(dgp, yn, yend); na[i] = ld(y1p, yn, yend); nbb[i] = ld(y2p, yn, yend);
-      if (WANT_DW) { nx1[i] = ld(x1p, yn - 1, yend - 1); nx2[i] = ld(x2p, yn - 1, yend - 1); }
-    }
 #pragma unroll
     for (int i = 0; i < PFG; ++i) {
       const int y = u.y0 + yy + i;
       const bool st = u.active && y < yend;
       gate_row(cg[i], ca[i], cb[i], p2, q2);
+      cg[i] = ld(dgp, y + PFG + 1, yend); ca[i] = ld(y1p, y + PFG + 1, yend); cb[i] = ld(y2p, y + PFG + 1, yend);
       if (o1p) {
         float o[4];
         stencil(w1, 0.f, p0, p1, p2, o);
@@ -332,16 +321,13 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
       if (WANT_DW) {
         float xr[4];
         R::expand(cx1[i], xr);
+        cx1[i] = ld(x1p, y + PFG, yend - 1);
         if (y < yend) wgrad_row(xr, p0, p1, p2, acc1);
         R::expand(cx2[i], xr);
+        cx2[i] = ld(x2p, y + PFG, yend - 1);
         if (y < yend) wgrad_row(xr, q0, q1, q2, acc2);
       }
       copy6(p0, p1); copy6(p1, p2); copy6(q0, q1); copy6(q1, q2);
-    }
-#pragma unroll
-    for (int i = 0; i < PFG; ++i) {
-      cg[i] = ng[i]; ca[i] = na[i]; cb[i] = nbb[i];
-      if (WANT_DW) { cx1[i] = nx1[i]; cx2[i] = nx2[i]; }
     }
   }
   if (WANT_DW) {
@@ -366,7 +352,7 @@ static int pick_band(int H, int64_t planes, int lpr) {
   }
   return 8;
 }
-struct Plan { int band, nb; unsigned blocks; };
+struct Plan { int band, nb; unsigned blocks; bool uni; };
 static Plan make_plan(int H, int W, int64_t planes) {
   const int lpr = W / 4, G = 64 / lpr;
   Plan p;
@@ -374,16 +360,20 @@ static Plan make_plan(int H, int W, int64_t planes) {
   p.nb = cdiv(H, p.band);
   const int64_t units = planes * p.nb;
   p.blocks = (unsigned)((units + 4 * G - 1) / (4 * G));
+  p.uni = p.nb % G == 0;
   return p;
 }
 
-#define DWS_LPR_SWITCH(W_, CALL)                     \
-  switch ((W_) / 4) {                                \
-    case 64: { constexpr int LPR = 64; CALL; } break; \
-    case 32: { constexpr int LPR = 32; CALL; } break; \
-    case 16: { constexpr int LPR = 16; CALL; } break; \
-    case 8: { constexpr int LPR = 8; CALL; } break;   \
-    default: { constexpr int LPR = 4; CALL; } break;  \
+#define DWS_UNI_SWITCH(LPR_, ...)                                                    \
+  if (p.uni) { constexpr int LPR = LPR_; constexpr bool UNI = true; __VA_ARGS__; }  \
+  else { constexpr int LPR = LPR_; constexpr bool UNI = false; __VA_ARGS__; }
+#define DWS_LPR_SWITCH(W_, ...)                                                              \
+  switch ((W_) / 4) {                                                                        \
+    case 64: { constexpr int LPR = 64; constexpr bool UNI = true; __VA_ARGS__; } break;      \
+    case 32: { DWS_UNI_SWITCH(32, __VA_ARGS__) } break;                                      \
+    case 16: { DWS_UNI_SWITCH(16, __VA_ARGS__) } break;                                      \
+    case 8: { DWS_UNI_SWITCH(8, __VA_ARGS__) } break;                                        \
+    default: { DWS_UNI_SWITCH(4, __VA_ARGS__) } break;                                       \
   }
 
 }  // namespace
@@ -402,8 +392,8 @@ int dws_fwd(const DwArgs& a, int B, bool gate, bool flip, int dtype, hipStream_t
   dim3 grid(p.blocks), block(256);
 #define DWS_FWD(T_)                                                                                                      \
   DWS_LPR_SWITCH(a.W, {                                                                                                  \
-    if (gate) hipLaunchKernelGGL((dws_fwd_kernel<T_, true, LPR>), grid, block, 0, st, a, (int)planes, p.nb, p.band, 0);  \
-    else hipLaunchKernelGGL((dws_fwd_kernel<T_, false, LPR>), grid, block, 0, st, a, (int)planes, p.nb, p.band, flip ? 1 : 0); \
+    if (gate) hipLaunchKernelGGL((dws_fwd_kernel<T_, true, LPR, UNI>), grid, block, 0, st, a, (int)planes, p.nb, p.band, 0);  \
+    else hipLaunchKernelGGL((dws_fwd_kernel<T_, false, LPR, UNI>), grid, block, 0, st, a, (int)planes, p.nb, p.band, flip ? 1 : 0); \
   })
   if (dtype == MI_F32) { DWS_FWD(float); } else { DWS_FWD(bf16); }
 #undef DWS_FWD
@@ -418,9 +408,9 @@ int dws_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want_dx, 
   dim3 grid(p.blocks), block(256);
 #define DWS_BWD(T_)                                                                                              \
   DWS_LPR_SWITCH(a.W, {                                                                                          \
-    if (want_dx) hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, true>), grid, block, 0, st, a, (const T_*)xin, part, \
+    if (want_dx) hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, UNI, true>), grid, block, 0, st, a, (const T_*)xin, part, \
                                     (int)planes, p.nb, p.band);                                                  \
-    else hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
+    else hipLaunchKernelGGL((dws_bwd_kernel<T_, LPR, UNI, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
                             (int)planes, p.nb, p.band);                                                          \
   })
   if (dtype == MI_F32) { DWS_BWD(float); } else { DWS_BWD(bf16); }
@@ -437,9 +427,9 @@ int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want
   dim3 grid(p.blocks), block(256);
 #define DWS_GB(T_)                                                                                                    \
   DWS_LPR_SWITCH(a.W, {                                                                                               \
-    if (want_dw) hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, true>), grid, block, 0, st, a, (const T_*)xin, part, \
+    if (want_dw) hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, UNI, true>), grid, block, 0, st, a, (const T_*)xin, part, \
                                     (int)planes, p.nb, p.band);                                                       \
-    else hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
+    else hipLaunchKernelGGL((dws_gate_bwd_kernel<T_, LPR, UNI, false>), grid, block, 0, st, a, (const T_*)xin, part,        \
                             (int)planes, p.nb, p.band);                                                               \
   })
   if (dtype == MI_F32) { DWS_GB(float); } else { DWS_GB(bf16); }
