@@ -69,6 +69,24 @@ def make_step(model, trainer, noisy, clean, use_dev_scalars):
     return step, loss_buf
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled per the gfx950 calibration in
+    profiles/r01_q_pmc_calibration_*.txt).  Counters cannot be collected from inside the timed process, so this is the
+    last profiled value, or None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    tot = n = 0.0
+    for name, row in table.items():
+        if f"{kernel}_kernel" in name:
+            tot += row["hbm_bytes_per_launch"] * row["launches"]
+            n += row["launches"]
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(cfg, patch: int):
     """One oracle training step (fwd + L1 + bwd) on a single patch, fp32, all host threads."""
     from oracle import restormer_ref as R
@@ -208,7 +226,7 @@ def main():
             "achieved": round(tfs if use_mfma else gbs, 2), "peak": mfma_peak if use_mfma else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if use_mfma else "GB/s",
             "frac": round((tfs / mfma_peak) if use_mfma else (gbs / HBM_PEAK_GBS), 4),
-            "traffic": None,
+            "traffic": pmc_traffic(name), "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes)",
             "launches_per_step": dom["launches"] // nprof,
             "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]),

@@ -24,8 +24,12 @@ ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the fla
 
 class FlatTrainer:
     def __init__(self, model: nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, process_group=None, overlap: bool = True):
+                 weight_decay: float = 1e-2, process_group=None, overlap: bool = True, host_update=None):
         self.model = model
+        # host_update(trainer, scale): test hook that stands in for the fused AdamW kernel when the gradient-bucketing /
+        # all-reduce bookkeeping is exercised on CPU tensors over gloo.  The product has no CPU update: without the hook,
+        # optimizer_step on CPU tensors raises.
+        self._host_update = host_update
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -143,14 +147,10 @@ class FlatTrainer:
         if self.flat_p.is_cuda:
             ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.step_count, self.betas,
                            self.eps, self.wd, scale, self.dev_scalars if use_dev_scalars else None)
-        else:  # host logic path for the CPU (gloo) tests of the distributed bookkeeping; not a product path
-            g = self.flat_g * scale
-            b1, b2 = self.betas
-            self.flat_p.mul_(1.0 - self.lr * self.wd)
-            self.flat_m.mul_(b1).add_(g, alpha=1 - b1)
-            self.flat_v.mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** self.step_count, math.sqrt(1 - b2 ** self.step_count)
-            self.flat_p.addcdiv_(self.flat_m, self.flat_v.sqrt() / bc2 + self.eps, value=-self.lr / bc1)
+        elif self._host_update is not None:
+            self._host_update(self, scale)
+        else:
+            raise RuntimeError("FlatTrainer.optimizer_step: parameters are not on an MI355X (no CPU optimizer path)")
 
 
 def cosine_warmup_lr(epoch: int, base_lr: float, warmup_epochs: int = 15, max_epochs: int = 150,

@@ -1,7 +1,8 @@
 """World-size-2 gloo test of the data-parallel trainer (image_restoration_amd/trainer.py): two ranks on half batches
 must end with the same parameters as one process on the whole batch with torch.optim.AdamW — which checks the flat
 parameter/gradient buffers, the stage-bucketed all-reduce launched from the backward hooks (overlap=True) and after
-backward (overlap=False), the folding of autograd-delivered gradients and the AdamW update.  CPU only; the blocks of
+backward (overlap=False), the folding of autograd-delivered gradients (the AdamW arithmetic
+itself is injected by this test: the product's update is a HIP kernel and refuses CPU tensors).  CPU only; the blocks of
 the stand-in network are plain torch layers because the HIP modules refuse CPU tensors by design."""
 import os
 import socket
@@ -31,6 +32,19 @@ class TinyNet(nn.Module):
         return self.out(d) + x
 
 
+def _host_adamw(tr, scale):
+    """AdamW on the trainer's flat host buffers: stands in for the fused HIP kernel (mi_adamw_step) so that the
+    bucketing / all-reduce bookkeeping can run on CPU tensors; the product itself has no CPU update."""
+    import math
+    g = tr.flat_g * scale
+    b1, b2 = tr.betas
+    tr.flat_p.mul_(1.0 - tr.lr * tr.wd)
+    tr.flat_m.mul_(b1).add_(g, alpha=1 - b1)
+    tr.flat_v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** tr.step_count, math.sqrt(1 - b2 ** tr.step_count)
+    tr.flat_p.addcdiv_(tr.flat_m, tr.flat_v.sqrt() / bc2 + tr.eps, value=-tr.lr / bc1)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -44,7 +58,7 @@ def _worker(rank, world, port, overlap, ret):
         from image_restoration_amd.trainer import FlatTrainer
         torch.manual_seed(0)
         model = TinyNet()
-        tr = FlatTrainer(model, lr=1e-2, overlap=overlap)
+        tr = FlatTrainer(model, lr=1e-2, overlap=overlap, host_update=_host_adamw)
         assert tr.world == world and len(tr.stages) == 4
         g = torch.Generator().manual_seed(1)
         x = torch.randn(4, 3, 8, 8, generator=g)
@@ -99,3 +113,10 @@ def test_cosine_warmup_schedule_closed_form():
     assert abs(cosine_warmup_lr(mid, 2e-4) - 1e-4) < 1e-12
     assert abs(cosine_warmup_lr(150, 2e-4)) < 1e-15
     assert abs(cosine_warmup_lr(60, 2e-4) - 0.5 * 2e-4 * (1 + math.cos(math.pi * 45 / 135))) < 1e-15
+
+
+def test_optimizer_step_has_no_cpu_path():
+    from image_restoration_amd.trainer import FlatTrainer
+    tr = FlatTrainer(TinyNet(), lr=1e-2)
+    with pytest.raises(RuntimeError, match="no CPU optimizer path"):
+        tr.optimizer_step()
