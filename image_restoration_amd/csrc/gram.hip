@@ -4,6 +4,9 @@
 // 1x1-conv weight gradient (sum over batch).  Both operands are pixel-contiguous, so both MFMA
 // fragments are plain 16-byte row reads from LDS.  The pixel axis is split across workgroups; partial
 // tiles go to a workspace and are summed in a fixed order by a second kernel (bitwise reproducible).
+#include <stdlib.h>
+
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -169,6 +172,175 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   }
 }
 
+// ---- bf16 streaming form ------------------------------------------------------------------------------------------------
+// Both operands are pixel-contiguous, and the MFMA k index may be ANY permutation of the pixels as long as A and B use
+// the same one - so a lane's fragment (row li, 8 consecutive pixels) is one plain 16-byte global load and nothing needs
+// LDS.  A wave owns the whole (16 FA) x (16 FB) tile over its own pixels: per 64-pixel step it loads the two halves of
+// one 128-byte line of each row (k-steps 0 and 1) and issues 2 FA FB MFMAs, with the next step's (FA + FB) x 2 loads
+// already in flight; the four waves of a workgroup take interleaved steps of the workgroup's pixel range and are summed
+// in a fixed order through LDS at the end.  No barrier in the streaming loop (the LDS-staged kernel above: two per chunk).
+template <int FA, int FB, bool SS>
+__global__ __launch_bounds__(256) void gram_stream_kernel(GramK p, int steps_per_block, int nsteps) {
+  using T = bf16;
+  __shared__ __attribute__((aligned(16))) f32x4 red[2][FA * FB][64];
+  __shared__ float ssm[SS ? 4 : 1][SS ? (FA + FB) * 16 : 1];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
+  const int i0 = ta * 16 * FA, j0 = tb * 16 * FB;
+  const T* A = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
+  const T* B = (const T*)p.b + zb * p.b_bs + zg * p.b_gs;
+  const int s_begin = blockIdx.x * steps_per_block;
+  const int s_end = min(s_begin + steps_per_block, nsteps);
+
+  const T* arow[FA];
+  const T* brow[FB];
+  bool aok[FA], bok[FB];
+#pragma unroll
+  for (int f = 0; f < FA; ++f) {
+    const int r = i0 + 16 * f + li;
+    aok[f] = r < p.ma;
+    arow[f] = A + (int64_t)(aok[f] ? r : 0) * p.n + 8 * g;
+  }
+#pragma unroll
+  for (int f = 0; f < FB; ++f) {
+    const int r = j0 + 16 * f + li;
+    bok[f] = r < p.mb;
+    brow[f] = B + (int64_t)(bok[f] ? r : 0) * p.n + 8 * g;
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_step = [&](int s, u32x4 (*av)[2], u32x4 (*bv)[2]) {
+    const int64_t px = (int64_t)s * 64 + 8 * g;          // this lane's first pixel of k-step 0; k-step 1 is 32 further
+    const bool in0 = s < s_end && px + 8 <= p.n, in1 = s < s_end && px + 40 <= p.n;
+#pragma unroll
+    for (int f = 0; f < FA; ++f) {
+      const u32x4* q = reinterpret_cast<const u32x4*>(arow[f] + (int64_t)s * 64);
+      av[f][0] = (aok[f] && in0) ? q[0] : zero4;
+      av[f][1] = (aok[f] && in1) ? q[4] : zero4;
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      const u32x4* q = reinterpret_cast<const u32x4*>(brow[f] + (int64_t)s * 64);
+      bv[f][0] = (bok[f] && in0) ? q[0] : zero4;
+      bv[f][1] = (bok[f] && in1) ? q[4] : zero4;
+    }
+  };
+
+  f32x4 acc[FA][FB];
+  float ssa[FA], ssb[FB];
+#pragma unroll
+  for (int a = 0; a < FA; ++a) {
+    ssa[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int b = 0; b < FB; ++b) ssb[b] = 0.f;
+
+  u32x4 ca[FA][2], cb[FB][2];
+  load_step(s_begin + wv, ca, cb);
+  for (int s = s_begin + wv; s < s_end; s += 4) {
+    u32x4 na[FA][2], nb[FB][2];
+    load_step(s + 4, na, nb);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s16x8 av[FA], bv[FB];
+#pragma unroll
+      for (int f = 0; f < FA; ++f) av[f] = __builtin_bit_cast(s16x8, ca[f][h]);
+#pragma unroll
+      for (int f = 0; f < FB; ++f) bv[f] = __builtin_bit_cast(s16x8, cb[f][h]);
+      if (SS) {
+#pragma unroll
+        for (int f = 0; f < FA; ++f)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = bf16_bits_to_f32((unsigned int)(unsigned short)av[f][e]);
+            ssa[f] += x * x;
+          }
+#pragma unroll
+        for (int f = 0; f < FB; ++f)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float y = bf16_bits_to_f32((unsigned int)(unsigned short)bv[f][e]);
+            ssb[f] += y * y;
+          }
+      }
+#pragma unroll
+      for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb)
+          acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < FA; ++f) { ca[f][0] = na[f][0]; ca[f][1] = na[f][1]; }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) { cb[f][0] = nb[f][0]; cb[f][1] = nb[f][1]; }
+  }
+
+  // fixed-order sum of the four waves: (w0 + w2) + (w1 + w3)
+  if (wv >= 2) {
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) red[wv - 2][fa * FB + fb][lane] = acc[fa][fb];
+  }
+  if (SS) {
+#pragma unroll
+    for (int f = 0; f < FA; ++f) {
+      float v = ssa[f];
+      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (g == 0) ssm[wv][16 * f + li] = v;
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      float v = ssb[f];
+      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (g == 0) ssm[wv][16 * (FA + f) + li] = v;
+    }
+  }
+  __syncthreads();
+  if (wv < 2) {
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const f32x4 o = red[wv][fa * FB + fb][lane];
+        acc[fa][fb] += o;
+      }
+  }
+  __syncthreads();
+  if (wv == 1) {
+#pragma unroll
+    for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) red[0][fa * FB + fb][lane] = acc[fa][fb];
+  }
+  __syncthreads();
+  if (wv != 0) return;
+  float* pz = p.part + ((int64_t)blockIdx.x * p.Z + z) * ((int64_t)p.ma * p.mb);
+#pragma unroll
+  for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+      const f32x4 o = acc[fa][fb] + red[0][fa * FB + fb][lane];
+      const int j = j0 + 16 * fb + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * fa + 4 * g + r;
+        if (i < p.ma && j < p.mb) pz[(int64_t)i * p.mb + j] = o[r];
+      }
+    }
+  if (SS && p.ss_part) {
+    float* sz = p.ss_part + ((int64_t)blockIdx.x * p.Z + z) * (p.ma + p.mb);
+    for (int e = lane; e < (FA + FB) * 16; e += 64) {
+      const float v = (ssm[0][e] + ssm[2][e]) + (ssm[1][e] + ssm[3][e]);
+      if (e < FA * 16) { const int i = i0 + e; if (tb == 0 && i < p.ma) sz[i] = v; }
+      else { const int j = j0 + e - FA * 16; if (ta == 0 && j < p.mb) sz[p.ma + j] = v; }
+    }
+  }
+}
+
 // out[zo][i*ld + j] (+)= sum_{split} sum_{b if sum_batch} part[split][b*groups+g][i][j]
 // 256 threads = 16 consecutive elements x 16 slice-phases; each thread walks its slices 4 at a time (loads in flight),
 // phases are combined through LDS in a fixed order (reproducible).
@@ -230,6 +402,50 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
   return g;
 }
 
+// streaming plan (bf16, 16-byte aligned rows): fragment counts per tile and the pixel split
+struct GramSPlan { int fa, fb, tiles_a, tiles_b, nsteps, spb, splits, Z; size_t part_bytes, ss_bytes; };
+static int gram_pick_frags(int m) {
+  int best = 3, best_pad = 1 << 30;
+  for (int f : {3, 4, 6}) {
+    const int pad = cdiv(m, 16 * f) * 16 * f;
+    if (pad < best_pad || (pad == best_pad && f > best)) { best = f; best_pad = pad; }
+  }
+  return best;
+}
+static GramSPlan gram_splan(const mi_gram_desc* d) {
+  GramSPlan g;
+  g.fa = gram_pick_frags(d->ma);
+  g.fb = gram_pick_frags(d->mb);
+  if (g.fa * g.fb > 24) { if (g.fa >= g.fb) g.fa = 3; else g.fb = 3; }  // 6x6 -> 3x6: accumulators + two stages of loads <= 256 VGPRs
+  g.tiles_a = cdiv(d->ma, 16 * g.fa);
+  g.tiles_b = cdiv(d->mb, 16 * g.fb);
+  g.Z = d->batch * d->groups;
+  g.nsteps = (int)cdiv(d->n, 64);
+  const int64_t tiles = (int64_t)g.tiles_a * g.tiles_b * g.Z;
+  int64_t want = 768 / (tiles > 0 ? tiles : 1);
+  const int64_t cap = g.nsteps / 32 > 0 ? g.nsteps / 32 : 1;   // >= 8 steps per wave: the prefetch pipeline needs a run
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  // several tiles re-read the same pixels: a split count that is a multiple of 8 puts them on one XCD (shared L2)
+  if (g.tiles_a * g.tiles_b > 1 && want >= 8) want = want / 8 * 8;
+  g.spb = (int)((cdiv(g.nsteps, want) + 3) / 4 * 4);
+  g.splits = (int)cdiv(g.nsteps, g.spb);
+  g.part_bytes = align_up((size_t)g.splits * g.Z * d->ma * d->mb * sizeof(float), 256);
+  g.ss_bytes = align_up((size_t)g.splits * g.Z * (d->ma + d->mb) * sizeof(float), 256);
+  return g;
+}
+static bool gram_stream_ok(const mi_gram_desc* d) {
+  if (d->dtype != MI_BF16 || getenv("MI_GRAM_LDS")) return false;
+  bool ok = (d->n % 8 == 0) && aligned16(d->a) && aligned16(d->b);
+  ok = ok && d->a_bs % 8 == 0 && d->a_gs % 8 == 0 && d->b_bs % 8 == 0 && d->b_gs % 8 == 0;
+  if (!ok) return false;
+  // Measured (profiles/r01_s_gram_microbench.log): the streaming form wins while one or a few SMALL tiles cover the
+  // output (48x48 q k^T, the 144/254/127 x 48 weight gradients: 1.1-1.7x); with 96-wide or many tiles the operand
+  // re-reads and 1-wave occupancy lose to the LDS-staged 128x128 tiles (0.6-0.85x).
+  const GramSPlan g = gram_splan(d);
+  return g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4 && d->n >= 4096;
+}
+
 static int gram_check(const mi_gram_desc* d) {
   MI_CHECK_ARG(d && d->a && d->b && d->out, "gram: null pointer");
   MI_CHECK_ARG(d->ma > 0 && d->mb > 0 && d->n > 0 && d->batch > 0 && d->groups > 0, "gram: bad shape");
@@ -243,17 +459,57 @@ static int gram_check(const mi_gram_desc* d) {
 
 using namespace mi;
 
+static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
+  const GramSPlan g = gram_splan(d);
+  GramK k;
+  k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
+  k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
+  k.n = d->n; k.groups = d->groups; k.Z = g.Z;
+  k.part = (float*)ws;
+  k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
+  k.chunks_per_split = 0; k.nchunks = 0; k.tiles_b = g.tiles_b; k.vec_ok = 1;
+  dim3 grid(g.splits, g.tiles_a * g.tiles_b, g.Z), block(256);
+  MI_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gram: grid too large");
+  const bool ss = d->sumsq != nullptr;
+  {
+    ProfScope ps(st, K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * 2.0 + 4.0 * g.splits * g.Z * d->ma * d->mb,
+                 2.0 * d->ma * d->mb * (double)d->n * g.Z);
+#define GS_CASE(FA_, FB_)                                                                                           \
+  if (g.fa == FA_ && g.fb == FB_) {                                                                                 \
+    if (ss) hipLaunchKernelGGL((gram_stream_kernel<FA_, FB_, true>), grid, block, 0, st, k, g.spb, g.nsteps);       \
+    else hipLaunchKernelGGL((gram_stream_kernel<FA_, FB_, false>), grid, block, 0, st, k, g.spb, g.nsteps);         \
+  }
+    GS_CASE(3, 3) else GS_CASE(3, 4) else GS_CASE(3, 6) else GS_CASE(4, 3) else GS_CASE(4, 4) else GS_CASE(4, 6)
+    else GS_CASE(6, 3) else GS_CASE(6, 4) else { MI_CHECK_ARG(false, "gram: no streaming tile %dx%d", g.fa, g.fb); }
+#undef GS_CASE
+  }
+  MI_LAUNCH_CHECK();
+  ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
+  const int zo = d->sum_batch ? d->groups : g.Z;
+  const int64_t per = (int64_t)d->ma * d->mb;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
+                     d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+  MI_LAUNCH_CHECK();
+  if (ss) {
+    const int64_t cols = (int64_t)g.Z * (d->ma + d->mb);
+    MI_TRY(launch_reduce_rows(k.ss_part, d->sumsq, g.splits, cols, cols, 0, 1.0f, st));
+  }
+  return MI_OK;
+}
+
 extern "C" size_t mi_gram_workspace(const mi_gram_desc* d) {
   if (!d || d->ma <= 0 || d->mb <= 0 || d->n <= 0 || d->batch <= 0 || d->groups <= 0) return 0;
   GramPlan g = gram_plan(d);
   // sumsq presence may differ between the sizing call and the real call: always reserve it
   const size_t ss = align_up((size_t)g.splits * g.Z * (d->ma + d->mb) * sizeof(float), 256);
-  return g.part_bytes + ss;
+  const GramSPlan sp = gram_splan(d);  // either kernel may run (alignment decides at call time): cover both
+  return std::max(g.part_bytes + ss, sp.part_bytes + sp.ss_bytes);
 }
 
 extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   MI_TRY(gram_check(d));
   MI_CHECK_ARG(ws, "gram: null workspace");
+  if (gram_stream_ok(d)) return gram_stream_launch(d, ws, (hipStream_t)stream);
   GramPlan g = gram_plan(d);
   hipStream_t st = (hipStream_t)stream;
   GramK k;
