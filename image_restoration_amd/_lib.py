@@ -96,6 +96,9 @@ SIGNATURES = {
                                      C.c_int, vp, vp]),
     "mi_pw_gemm_workspace": (C.c_size_t, [C.POINTER(PwDesc)]),
     "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp, vp]),
+    "mi_pw_cache_enable": (C.c_int, [vp, C.c_size_t]),
+    "mi_pw_cache_refresh": (C.c_int, [vp]),
+    "mi_pw_cache_invalidate": (C.c_int, []),
     "mi_gram_workspace": (C.c_size_t, [C.POINTER(GramDesc)]),
     "mi_gram": (C.c_int, [C.POINTER(GramDesc), vp, vp]),
     "mi_mdta_saved_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),

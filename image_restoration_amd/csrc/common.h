@@ -209,6 +209,7 @@ struct ProfScope {
 // generic small kernels implemented in util.hip, used by several modules
 constexpr int REDUCE_GROUPS = 32;
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld,
-                       int accumulate, float scale, hipStream_t st, float* tmp = nullptr);
+                       int accumulate, float scale, hipStream_t st, float* tmp = nullptr, float* out2 = nullptr,
+                       int64_t split = 0);  // out2: columns [split, cols) are written to out2[0 .. cols-split)
 
 }  // namespace mi

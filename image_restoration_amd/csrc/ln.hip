@@ -344,8 +344,9 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
                                                   (bf16*)dx, part, B, C, N, &rows, st);
   }
   if (rc != MI_OK) return rc;
-  float* tmp = part + (int64_t)rows * 2 * C;  // two-stage scratch: [REDUCE_GROUPS][C] for dw, then the same for db
-  MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st, tmp));
-  if (with_bias) MI_TRY(launch_reduce_rows(part + C, db, rows, C, 2 * C, accumulate, 1.0f, st, tmp + (size_t)REDUCE_GROUPS * C));
+  float* tmp = part + (int64_t)rows * 2 * C;  // two-stage scratch: [REDUCE_GROUPS][2C]
+  // d gamma and d beta are adjacent column blocks of the partial rows: one reduction writes both tensors
+  if (with_bias) MI_TRY(launch_reduce_rows(part, dw, rows, 2 * C, 2 * C, accumulate, 1.0f, st, tmp, db, C));
+  else MI_TRY(launch_reduce_rows(part, dw, rows, C, 2 * C, accumulate, 1.0f, st, tmp));
   return MI_OK;
 }

@@ -10,7 +10,10 @@
 // bf16 activations use v_mfma_f32_16x16x32_bf16, fp32 activations the exact v_mfma_f32_16x16x4_f32.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "internal.h"
 
@@ -29,6 +32,14 @@ __device__ __forceinline__ s16x4 lds_tr_b16(const void* p) {
   return v;
 }
 
+// LDS operations of one wave execute in issue order; this only keeps the compiler from reordering across the point
+// (wave-private LDS exchange without a workgroup barrier).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T, int TM> struct PwImg {
   static constexpr int WS_ROW = PwRow<T>::WS_ROW;
   static constexpr int W_BYTES = TM * WS_ROW * (int)sizeof(T);
@@ -38,30 +49,49 @@ template <typename T, int TM> struct PwImg {
 constexpr int PW_ZERO_BYTES = 256;  // zero block at the head of the workspace: LDS-DMA source for out-of-range rows/cols
 
 // ---- weight re-pack: fp32 W(m,k) (any strides) -> T image [slice][m_tile][k_chunk][chunk stride] of [TM][WS_ROW] ----
+struct PackJob {          // one weight matrix -> one packed image (device-visible: the batched refresh reads a table of these)
+  const float* w; int64_t w_bs, w_gs, w_sm, w_sk;
+  unsigned char* ws;      // [zero block][packed image]
+  int M, K, tm, k_chunks, groups_w, chunk_elems, m_fast, dtype, slices;
+  int64_t slice_elems;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void pw_pack_kernel(const float* __restrict__ w, int64_t w_bs, int64_t w_gs, int64_t w_sm,
-                                                      int64_t w_sk, unsigned char* __restrict__ ws, int M, int K, int tm,
-                                                      int k_chunks, int groups_w, int64_t slice_elems, int chunk_elems,
-                                                      int m_fast) {
+__device__ __forceinline__ void pw_pack_slice(const PackJob& j, int slice, int64_t first, int64_t stride) {
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < PW_ZERO_BYTES / 4) reinterpret_cast<float*>(ws)[threadIdx.x] = 0.f;
-  T* out = reinterpret_cast<T*>(ws + PW_ZERO_BYTES);
-  const int slice = blockIdx.y;
-  const int sb = slice / groups_w, sg = slice - sb * groups_w;
-  const float* wz = w + sb * w_bs + sg * w_gs;
-  T* oz = out + (int64_t)slice * slice_elems;
-  const int m_tiles = (int)(slice_elems / ((int64_t)k_chunks * chunk_elems));
+  T* out = reinterpret_cast<T*>(j.ws + PW_ZERO_BYTES);
+  const int sb = slice / j.groups_w, sg = slice - sb * j.groups_w;
+  const float* wz = j.w + sb * j.w_bs + sg * j.w_gs;
+  T* oz = out + (int64_t)slice * j.slice_elems;
+  const int tm = j.tm, k_chunks = j.k_chunks;
+  const int m_tiles = (int)(j.slice_elems / ((int64_t)k_chunks * j.chunk_elems));
   const int64_t total = (int64_t)m_tiles * k_chunks * tm * PW_KC;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = first; e < total; e += stride) {
     // m_fast: consecutive threads walk m (coalesced for W^T callers), else k
     int64_t r = e;
     int kk, mm;
-    if (m_fast) { mm = (int)(r % tm); r /= tm; kk = (int)(r % PW_KC); r /= PW_KC; }
+    if (j.m_fast) { mm = (int)(r % tm); r /= tm; kk = (int)(r % PW_KC); r /= PW_KC; }
     else { kk = (int)(r % PW_KC); r /= PW_KC; mm = (int)(r % tm); r /= tm; }
     const int kc = (int)(r % k_chunks), mt = (int)(r / k_chunks);
     const int m = mt * tm + mm, k = kc * PW_KC + kk;
-    const float v = (m < M && k < K) ? wz[(int64_t)m * w_sm + (int64_t)k * w_sk] : 0.f;
-    oz[((int64_t)mt * k_chunks + kc) * chunk_elems + mm * WS_ROW + kk] = Cvt<T>::from(v);
+    const float v = (m < j.M && k < j.K) ? wz[(int64_t)m * j.w_sm + (int64_t)k * j.w_sk] : 0.f;
+    oz[((int64_t)mt * k_chunks + kc) * j.chunk_elems + mm * WS_ROW + kk] = Cvt<T>::from(v);
+  }
+}
+
+// ---- weight re-pack: fp32 W(m,k) (any strides) -> T image [slice][m_tile][k_chunk][chunk stride] of [TM][WS_ROW] ----
+template <typename T>
+__global__ __launch_bounds__(256) void pw_pack_kernel(PackJob j) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < PW_ZERO_BYTES / 4) reinterpret_cast<float*>(j.ws)[threadIdx.x] = 0.f;
+  pw_pack_slice<T>(j, blockIdx.y, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+// every cached weight of the model in ONE launch (mi_pw_cache_refresh): blockIdx.y = table entry
+__global__ __launch_bounds__(256) void pw_pack_table_kernel(const PackJob* __restrict__ table) {
+  const PackJob j = table[blockIdx.y];
+  if (blockIdx.x == 0 && threadIdx.x < PW_ZERO_BYTES / 4) reinterpret_cast<float*>(j.ws)[threadIdx.x] = 0.f;
+  for (int slice = 0; slice < j.slices; ++slice) {
+    if (j.dtype == MI_F32) pw_pack_slice<float>(j, slice, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+    else pw_pack_slice<bf16>(j, slice, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
   }
 }
 
@@ -84,11 +114,13 @@ template <typename T, bool DMA> struct PwXAddr {
 };
 
 // one 32-deep chunk of MFMAs: acc[nf][mf] += X^T(pixels 16nf.., k) * W^T(k, channels mw+16mf..)
-template <typename T, int MF, bool DMA>
+template <typename T, int MF, bool DMA, int XS = PW_XS>
 __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*acc)[MF], int mw, int li, int g) {
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
-  using XA = PwXAddr<T, DMA>;
+  struct XA {
+    static __device__ __forceinline__ int at(int r, int n) { return DMA ? PwXAddr<T, DMA>::at(r, n) : r * XS + n; }
+  };
   if constexpr (F32) {
 #pragma unroll
     for (int ks = 0; ks < PW_KC / 4; ++ks) {
@@ -287,6 +319,150 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
   pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_raw), acc, zb, zg, m0, n0, mw, lane, wv);
 }
 
+// ---- big-tile form: 128 channels x 128 pixels per workgroup, waves 2 x 2 (64 x 64 each), two LDS stages ----------------
+// For M >= ~100 the 64-pixel tiles above re-stage each 128 x 32 weight chunk for every 64 pixels and give a wave 8 MFMAs
+// per 12 fragment reads; here the weight chunk serves 128 pixels, a wave issues 16 MFMAs per 16 fragment reads, and the
+// two stages need ONE barrier per chunk (the next chunk is written while the current one is multiplied).  The epilogue
+// slabs are wave-private (no workgroup barriers after the first).
+constexpr int PWB_TN = 128, PWB_TM = 128, PWB_XS = 144;
+template <typename T>
+__global__ __launch_bounds__(256) void pw_gemm_big_kernel(PwG q) {
+  const PwK& p = q.k;
+  constexpr bool F32 = std::is_same<T, float>::value;
+  using IM = PwImg<T, PWB_TM>;
+  constexpr int X_ELEMS = PW_KC * PWB_XS, W_ELEMS = PWB_TM * IM::WS_ROW;
+  constexpr int STAGE_ELEMS = X_ELEMS + W_ELEMS;
+  constexpr int OS = 64 + 4;                                     // fp32 slab row stride
+  constexpr int SLAB_BYTES = 4 * 16 * OS * (int)sizeof(float);
+  constexpr int LDS_BYTES = 2 * STAGE_ELEMS * (int)sizeof(T) > SLAB_BYTES ? 2 * STAGE_ELEMS * (int)sizeof(T) : SLAB_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  T* const stage0 = reinterpret_cast<T*>(lds_raw);
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int mw = (wv >> 1) * 64, nw = (wv & 1) * 64;             // this wave's channel / pixel offset inside the tile
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int64_t n0 = (int64_t)blockIdx.x * PWB_TN;
+  const int m0 = blockIdx.y * PWB_TM;
+  const int ktot = p.k1 + p.k2;
+  const int nchunks = q.k_chunks;
+  const T* x1 = (const T*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  const T* x2 = p.x2 ? (const T*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : nullptr;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  const T* wpk = reinterpret_cast<const T*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
+                 (int64_t)blockIdx.y * nchunks * IM::W_PAD_ELEMS;
+
+  constexpr int EPVX = 16 / (int)sizeof(T);                      // elements per 16-byte vector
+  constexpr int XVR = PWB_TN / EPVX;                             // vectors per X row: 16 (bf16) / 32 (fp32)
+  constexpr int XV = PW_KC * XVR / 256;                          // vectors per thread: 2 / 4
+  constexpr int W_VECS = IM::W_BYTES / 16;
+  constexpr int WV = (W_VECS + 255) / 256;
+  u32x4 xreg[XV], wreg[WV];
+  auto load_stage = [&](int chunk) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int vid = t + 256 * v;
+      const int kr = vid / XVR, col = (vid % XVR) * EPVX;
+      const int k = chunk * PW_KC + kr;
+      const T* row = nullptr;
+      if (k < p.k1) row = x1 + (int64_t)k * p.n;
+      else if (k < ktot) row = x2 + (int64_t)(k - p.k1) * p.n;
+      const int64_t nn = n0 + col;
+      if (row && p.vec_ok && nn < p.n) {
+        xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
+      } else {
+        __attribute__((aligned(16))) T tmp[EPVX];
+#pragma unroll
+        for (int j = 0; j < EPVX; ++j) tmp[j] = (row && nn + j < p.n) ? row[nn + j] : Cvt<T>::from(0.f);
+        xreg[v] = *reinterpret_cast<u32x4*>(tmp);
+      }
+    }
+    const u32x4* wc = reinterpret_cast<const u32x4*>(wpk + (int64_t)chunk * IM::W_PAD_ELEMS);
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wreg[i] = wc[vid];
+    }
+  };
+  auto write_stage = [&](T* st) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int vid = t + 256 * v;
+      const int kr = vid / XVR, col = (vid % XVR) * EPVX;
+      *reinterpret_cast<u32x4*>(&st[kr * PWB_XS + col]) = xreg[v];
+    }
+    u32x4* wd = reinterpret_cast<u32x4*>(st + X_ELEMS);
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int vid = t + 256 * i;
+      if (vid < W_VECS) wd[vid] = wreg[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_stage(0);
+  write_stage(stage0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    T* cur = stage0 + (c & 1) * STAGE_ELEMS;
+    if (c + 1 < nchunks) load_stage(c + 1);
+    pw_chunk_mma<T, 4, false, PWB_XS>(cur + nw, cur + X_ELEMS, acc, mw, li, g);
+    if (c + 1 < nchunks) write_stage(stage0 + ((c + 1) & 1) * STAGE_ELEMS);
+    __syncthreads();   // chunk c+1 is in place; everyone is done with chunk c's stage (it is overwritten in iteration c+1)
+  }
+
+  // epilogue: wave-private 16 x 64 fp32 slab -> whole 128-byte (bf16) / 256-byte (fp32) row segments
+  T* yz = (T*)p.y + zb * p.y_bs + zg * p.y_gs;
+  const T* rz = p.r ? (const T*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
+  const float* bz = p.bias ? p.bias + zg * p.bias_gs : nullptr;
+  constexpr int EPV = F32 ? 4 : 8;
+  constexpr int LPR = 64 / EPV, RPI = 64 / LPR;
+  float* slab = reinterpret_cast<float*>(lds_raw) + wv * 16 * OS;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    wave_lds_sync();
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      float o[4] = {acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]};
+      Vec<float, 4>::st(&slab[li * OS + 16 * nf + 4 * g], o);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 16 / RPI; ++it) {
+      const int row = it * RPI + lane / LPR, col = (lane % LPR) * EPV;
+      const int m = m0 + mw + 16 * mf + row;
+      const int64_t n = n0 + nw + col;
+      if (m < p.m && n < p.n) {
+        float o[EPV];
+#pragma unroll
+        for (int v = 0; v < EPV / 4; ++v) Vec<float, 4>::ld(&slab[row * OS + col + 4 * v], o + 4 * v);
+        const float bv = bz ? bz[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) o[j] += bv;
+        const int64_t off = (int64_t)m * p.n + n;
+        if (p.vec_ok) {
+          if (rz) {
+            float rr[EPV];
+            Vec<T, EPV>::ld(rz + off, rr);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) o[j] += rr[j];
+          }
+          Vec<T, EPV>::st(yz + off, o);
+        } else {
+#pragma unroll
+          for (int j = 0; j < EPV; ++j)
+            if (n + j < p.n) st1(yz + off + j, o[j] + (rz ? ld1(rz + off + j) : 0.f));
+        }
+      }
+    }
+  }
+}
+
 // ---- LDS-DMA form (16-byte aligned rows): global_load_lds_dwordx4 straight into a 3-deep ring of chunk images, two
 // chunks in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier per chunk; no staging registers, no ds_write.
 template <typename T, int MF>
@@ -403,20 +579,66 @@ static int pw_launch_dma(const PwG& q, dim3 grid, hipStream_t st) {
   return MI_OK;
 }
 
+// ---- opt-in packed-weight cache (mi_pw_cache_*) -----------------------------------------------------------------------------
+// Every static 1x1 weight is packed once per use, i.e. ~260 seven-microsecond launches per Restormer training step whose
+// inputs only change at the optimizer step.  A caller that owns the weights' lifetime (the trainer) can lend the library
+// a device buffer: packed images then live there, keyed by (pointer, shape, strides, tiling), and ONE launch
+// (mi_pw_cache_refresh, right after the optimizer step) re-packs them all.  Disabled by default: without it every call
+// packs into its own workspace and the library keeps no state.
+struct PwCache {
+  std::mutex mu;
+  unsigned char* base = nullptr;
+  size_t bytes = 0, used = 0, table_bytes = 0;
+  std::vector<PackJob> jobs;
+  bool dirty = false;   // host table newer than the device copy
+  bool valid = false;   // packed images match the weights (set by refresh, cleared by invalidate / new entries)
+};
+static PwCache g_pwc;
+constexpr size_t PWC_TABLE_ENTRIES = 4096;
+
+static bool same_job(const PackJob& a, const PackJob& b) {
+  return a.w == b.w && a.w_bs == b.w_bs && a.w_gs == b.w_gs && a.w_sm == b.w_sm && a.w_sk == b.w_sk && a.M == b.M &&
+         a.K == b.K && a.tm == b.tm && a.dtype == b.dtype && a.groups_w == b.groups_w && a.slices == b.slices &&
+         a.chunk_elems == b.chunk_elems;
+}
+// Returns the cached image of this job if it is current; otherwise registers the job (so that the next refresh covers
+// it) and returns null: the caller then packs into its own workspace as usual.
+static const unsigned char* pw_cache_lookup(const PackJob& j, size_t image_bytes, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_pwc.mu);
+  if (!g_pwc.base || j.w_bs != 0) return nullptr;                 // per-image weights are never cached
+  for (const PackJob& e : g_pwc.jobs)
+    if (same_job(e, j)) return g_pwc.valid && !g_pwc.dirty ? e.ws : nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;  // no new entries mid-capture
+  const size_t need = align_up(image_bytes, 256);
+  if (g_pwc.jobs.size() >= PWC_TABLE_ENTRIES || g_pwc.used + need > g_pwc.bytes) return nullptr;      // full: stay uncached
+  PackJob e = j;
+  e.ws = g_pwc.base + g_pwc.used;
+  g_pwc.used += need;
+  g_pwc.jobs.push_back(e);
+  g_pwc.dirty = true;
+  return nullptr;
+}
+
 template <typename T>
 static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* ws, hipStream_t st) {
-  {  // re-pack the weights of every slice (and refresh the zero block)
+  PackJob job;
+  job.w = d->w; job.w_bs = d->w_bs; job.w_gs = d->w_gs; job.w_sm = d->w_sm; job.w_sk = d->w_sk;
+  job.ws = (unsigned char*)ws;
+  job.M = d->m; job.K = d->k1 + d->k2; job.tm = pl.tm; job.k_chunks = pl.k_chunks;
+  job.groups_w = pl.per_group ? d->groups : 1; job.chunk_elems = pl.chunk_elems; job.m_fast = d->w_sk != 1 ? 1 : 0;
+  job.dtype = d->dtype; job.slices = pl.slices; job.slice_elems = pl.slice_elems;
+  const unsigned char* cached = pw_cache_lookup(job, pl.bytes, st);
+  if (!cached) {  // re-pack the weights of every slice (and refresh the zero block)
     const int64_t total = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * PW_KC;
     int gx = cdiv(total, 256);
     if (gx > 1024) gx = 1024;
     ProfScope ps(st, K_PW_PACK, 4.0 * d->m * (d->k1 + d->k2) * pl.slices + (double)pl.bytes, 0.0);
-    hipLaunchKernelGGL((pw_pack_kernel<T>), dim3(gx, pl.slices), dim3(256), 0, st, d->w, d->w_bs, d->w_gs, d->w_sm, d->w_sk,
-                       (unsigned char*)ws, d->m, d->k1 + d->k2, pl.tm, pl.k_chunks, pl.per_group ? d->groups : 1,
-                       pl.slice_elems, pl.chunk_elems, d->w_sk != 1 ? 1 : 0);
+    hipLaunchKernelGGL((pw_pack_kernel<T>), dim3(gx, pl.slices), dim3(256), 0, st, job);
     MI_LAUNCH_CHECK();
   }
   PwG q;
-  q.k = k; q.ws = (const unsigned char*)ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch;
+  q.k = k; q.ws = cached ? cached : (const unsigned char*)ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch;
   q.wp_per_group = pl.per_group; q.k_chunks = pl.k_chunks;
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
@@ -430,6 +652,9 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   if (k.vec_ok && dma) {
     if (pl.tm == 128) MI_TRY((pw_launch_dma<T, 2>(q, grid, st)));
     else MI_TRY((pw_launch_dma<T, 1>(q, grid, st)));
+  } else if (pl.tm == 128 && std::is_same<T, bf16>::value && !getenv("MI_PW_SMALL_TILE")) {
+    dim3 bgrid(cdiv(k.n, PWB_TN), pl.m_tiles, grid.z);   // (fp32 would need 70 KB of static LDS: it keeps the 64-pixel tiles)
+    hipLaunchKernelGGL((pw_gemm_big_kernel<bf16>), bgrid, block, 0, st, q);
   } else {
     if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((pw_gemm_kernel<T, 1>), grid, block, 0, st, q);
@@ -475,4 +700,50 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == MI_F32) return pw_launch<float>(d, k, pl, ws, st);
   return pw_launch<bf16>(d, k, pl, ws, st);
+}
+
+extern "C" int mi_pw_cache_enable(void* buf, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pwc.mu);
+  g_pwc.jobs.clear();
+  g_pwc.valid = false; g_pwc.dirty = false; g_pwc.used = 0; g_pwc.base = nullptr; g_pwc.bytes = 0;
+  if (!buf) return MI_OK;  // disable
+  g_pwc.table_bytes = align_up(PWC_TABLE_ENTRIES * sizeof(PackJob), 256);
+  MI_CHECK_ARG(aligned16(buf) && bytes > g_pwc.table_bytes + 4096, "pw_cache_enable: buffer too small or misaligned");
+  g_pwc.base = (unsigned char*)buf; g_pwc.bytes = bytes; g_pwc.used = g_pwc.table_bytes;  // the job table sits at the head
+  return MI_OK;
+}
+
+extern "C" int mi_pw_cache_invalidate(void) {
+  std::lock_guard<std::mutex> lk(g_pwc.mu);
+  g_pwc.valid = false;
+  return MI_OK;
+}
+
+extern "C" int mi_pw_cache_refresh(void* stream) {
+  std::lock_guard<std::mutex> lk(g_pwc.mu);
+  if (!g_pwc.base || g_pwc.jobs.empty()) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_pwc.dirty) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    MI_CHECK_ARG(!(hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone),
+                 "pw_cache_refresh: new weights were registered; refresh once outside stream capture first");
+    MI_CHECK_HIP(hipMemcpyAsync(g_pwc.base, g_pwc.jobs.data(), g_pwc.jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, st));
+    MI_CHECK_HIP(hipStreamSynchronize(st));  // the host vector may be reallocated by a later registration
+    g_pwc.dirty = false;
+  }
+  int64_t most = 0;
+  double bytes = 0.0;
+  for (const PackJob& j : g_pwc.jobs) {
+    const int64_t total = j.slice_elems / j.chunk_elems * j.tm * PW_KC;
+    if (total > most) most = total;
+    bytes += 4.0 * j.M * j.K * j.slices + (double)j.slices * j.slice_elems * dtype_size(j.dtype);
+  }
+  int gx = cdiv(most, 256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  ProfScope ps(st, K_PW_PACK, bytes, 0.0);
+  hipLaunchKernelGGL(pw_pack_table_kernel, dim3(gx, (unsigned)g_pwc.jobs.size()), dim3(256), 0, st, (const PackJob*)g_pwc.base);
+  MI_LAUNCH_CHECK();
+  g_pwc.valid = true;
+  return MI_OK;
 }

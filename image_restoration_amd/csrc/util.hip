@@ -48,7 +48,8 @@ ProfScope::~ProfScope() {
 // Row group g = blockIdx.y covers rows [g*rpg, min(rows, (g+1)*rpg)) and writes out + g*out_gs.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                           int64_t rows, int64_t cols, int64_t ld, int accumulate,
-                                                          float scale, int64_t rpg, int64_t out_gs) {
+                                                          float scale, int64_t rpg, int64_t out_gs,
+                                                          float* __restrict__ out2, int64_t split) {
   __shared__ float sm[8][32];
   const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + cx;
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += sm[k][cx];
-    float* o = out + (int64_t)blockIdx.y * out_gs + c;
+    // columns [split, cols) go to a second tensor (two parameter gradients reduced by one launch)
+    float* o = (out2 && c >= split) ? out2 + (c - split) : out + (int64_t)blockIdx.y * out_gs + c;
     *o = (accumulate ? *o : 0.f) + scale * t;
   }
 }
@@ -80,21 +82,21 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // tmp (optional, REDUCE_GROUPS*cols floats): when given and rows is large the sum runs in two stages so that the
 // long row walk is spread over REDUCE_GROUPS x (cols/32) workgroups instead of cols/32.
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate,
-                       float scale, hipStream_t st, float* tmp) {
+                       float scale, hipStream_t st, float* tmp, float* out2, int64_t split) {
   if (cols <= 0) return MI_OK;
   if (tmp && rows > 4 * REDUCE_GROUPS) {
     const int64_t rpg = (rows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
     {
       ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + REDUCE_GROUPS) * cols * 4, (double)rows * cols);
       hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32), REDUCE_GROUPS), dim3(256), 0, st, part, tmp, rows, cols,
-                         part_ld, 0, 1.0f, rpg, cols);
+                         part_ld, 0, 1.0f, rpg, cols, (float*)nullptr, (int64_t)0);
     }
     MI_LAUNCH_CHECK();
     part = tmp; rows = REDUCE_GROUPS; part_ld = cols;
   }
   ProfScope ps(st, K_REDUCE_ROWS, (double)(rows + 1) * cols * 4, (double)rows * cols);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(cols, 32), 1), dim3(256), 0, st, part, out, rows, cols, part_ld,
-                     accumulate, scale, rows, (int64_t)0);
+                     accumulate, scale, rows, (int64_t)0, out2, split);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -198,12 +200,18 @@ extern "C" int mi_prof_collect(double* ms, double* bytes, double* flops, int64_t
   MI_CHECK_ARG(ms && bytes && flops && launches && n >= K_COUNT, "prof_collect: need arrays of %d entries", K_COUNT);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < n; ++i) { ms[i] = 0; bytes[i] = 0; flops[i] = 0; launches[i] = 0; }
+  // MI_PROF_TRACE=<file>: also append one line per launch (kernel, algorithmic bytes, flops, ms) - the bytes/flops pair
+  // identifies the shape, which is how the per-shape tables in profiles/ are made
+  const char* trace_path = getenv("MI_PROF_TRACE");
+  FILE* trace = trace_path ? fopen(trace_path, "a") : nullptr;
   for (auto& r : g_prof_recs) {
     MI_CHECK_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     MI_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
     ms[r.kid] += t; bytes[r.kid] += r.bytes; flops[r.kid] += r.flops; launches[r.kid] += 1;
+    if (trace) fprintf(trace, "%s %.0f %.0f %.6f\n", g_kernel_names[r.kid], r.bytes, r.flops, (double)t);
   }
+  if (trace) fclose(trace);
   return MI_OK;
 }
 extern "C" const char* mi_last_error(void) { return g_err; }

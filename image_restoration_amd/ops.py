@@ -344,6 +344,30 @@ def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
 
 
 # ----------------------------------------------------------------------------- profiler (bench.py roofline pass)
+_pw_cache_buf: Optional[Tensor] = None
+
+
+def pw_cache_enable(nbytes: int, device) -> None:
+    """Lend the library a device buffer for packed 1x1 weights (include/mi_restore.h: mi_pw_cache_*).  The caller
+    promises to call pw_cache_refresh() after every in-place weight update (or pw_cache_invalidate())."""
+    global _pw_cache_buf
+    if nbytes <= 0:
+        L.check(L.lib().mi_pw_cache_enable(None, 0), "pw_cache_enable")
+        _pw_cache_buf = None
+        return
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    L.check(L.lib().mi_pw_cache_enable(buf.data_ptr(), nbytes), "pw_cache_enable")
+    _pw_cache_buf = buf  # keeps the memory alive for as long as the cache points at it
+
+
+def pw_cache_refresh() -> None:
+    L.check(L.lib().mi_pw_cache_refresh(_stream()), "pw_cache_refresh")
+
+
+def pw_cache_invalidate() -> None:
+    L.check(L.lib().mi_pw_cache_invalidate(), "pw_cache_invalidate")
+
+
 def prof_enable(on: bool) -> None:
     L.check(L.lib().mi_prof_enable(int(on)), "prof_enable")
 

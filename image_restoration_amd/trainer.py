@@ -24,7 +24,8 @@ ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the fla
 
 class FlatTrainer:
     def __init__(self, model: nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, process_group=None, overlap: bool = True, host_update=None):
+                 weight_decay: float = 1e-2, process_group=None, overlap: bool = True, host_update=None,
+                 pack_cache: bool = True):
         self.model = model
         # host_update(trainer, scale): test hook that stands in for the fused AdamW kernel when the gradient-bucketing /
         # all-reduce bookkeeping is exercised on CPU tensors over gloo.  The product has no CPU update: without the hook,
@@ -76,6 +77,12 @@ class FlatTrainer:
             for idx, (_, child, _, _) in enumerate(self.stages):
                 child.register_forward_hook(self._make_fwd_hook(idx))
         self.dev_scalars = torch.zeros(3, dtype=torch.float32, device=dev) if dev.type == "cuda" else None
+        # The trainer is the only writer of the parameters, so it can let the library keep the packed (bf16, LDS-image)
+        # copies of all 1x1 weights across calls and refresh them once per optimizer step (mi_pw_cache_*): 4 bytes of
+        # cache per parameter covers both orientations of every matrix in either activation dtype, plus tile padding.
+        self._pack_cache = bool(pack_cache) and dev.type == "cuda"
+        if self._pack_cache:
+            ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev)
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self) -> None:
@@ -147,6 +154,8 @@ class FlatTrainer:
         if self.flat_p.is_cuda:
             ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.step_count, self.betas,
                            self.eps, self.wd, scale, self.dev_scalars if use_dev_scalars else None)
+            if self._pack_cache:
+                ops.pw_cache_refresh()   # the weights just changed: re-pack every 1x1 weight image in one launch
         elif self._host_update is not None:
             self._host_update(self, scale)
         else:

@@ -18,8 +18,9 @@
  *  - every call takes the HIP stream to launch on (hipStream_t as void*).
  *  - return 0 on success, negative on failure; mi_last_error() gives the
  *    message (thread local).  No exceptions or aborts cross the ABI.
- *  - thread-safe: no global mutable state except the thread-local error string
- *    (backward is called from autograd worker threads).
+ *  - thread-safe: no global mutable state except the thread-local error string,
+ *    the profiler and the opt-in packed-weight cache (mi_pw_cache_*), both mutex
+ *    protected (backward is called from autograd worker threads).
  */
 #ifndef MI_RESTORE_H
 #define MI_RESTORE_H
@@ -103,6 +104,22 @@ typedef struct {
 } mi_pw_desc;
 size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
 int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
+
+/* Opt-in packed-weight cache.  By default every mi_pw_gemm (and every module entry point built on it) packs its weight
+ * matrix into its own workspace, once per call, and the library keeps no state.  A caller that controls when the
+ * weights change (a trainer: only at the optimizer step; an inference server: never) may lend a device buffer:
+ *   mi_pw_cache_enable(buf, bytes)  buf stays owned by the caller and must outlive the cache; NULL disables it.
+ *   mi_pw_cache_refresh(stream)     re-packs EVERY weight seen so far in one launch; from then on calls with those
+ *                                   weights skip their pack launch.  Call it after each optimizer step (the weights
+ *                                   registered since the last refresh are picked up; the first refresh after new
+ *                                   registrations must run outside stream capture).
+ *   mi_pw_cache_invalidate()        packed images are stale (weights were overwritten some other way): calls pack
+ *                                   per call again until the next refresh.
+ * Per-image weights (w_bs != 0) are never cached.  The cache is process-global and mutex-protected; this is the only
+ * mutable state in the library besides the thread-local error string and the profiler.                              */
+int mi_pw_cache_enable(void* buf, size_t bytes);
+int mi_pw_cache_refresh(void* stream);
+int mi_pw_cache_invalidate(void);
 
 /* ------------------------------------------------------------------------
  * Row-Gram (reduction over the pixel axis), the contraction of MDTA's q k^T

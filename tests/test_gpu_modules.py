@@ -157,3 +157,51 @@ def test_restormer_tiny_config_c1_and_psnr():
     params = dict(net.named_parameters())
     got = np.array([float(params[k].grad.norm()) for k in keys])
     assert np.all(np.abs(got - ref) <= 1e-3 * np.maximum(ref, 1e-12) + 1e-9), np.abs(got / ref - 1).max()
+
+
+def test_packed_weight_cache_is_transparent():
+    """mi_pw_cache_*: with the cache on, results are bit-identical to per-call packing, before and after an in-place
+    weight update followed by refresh; a stale cache is avoided by invalidate."""
+    from image_restoration_amd import ops
+    m = M()
+    c, heads, shape = 48, 1, (2, 48, 16, 16)
+    sd = R.make_block_state(c, heads, 2.66, True, "WithBias", seed=8)
+    x, cot = seeded_input(shape, 930), seeded_input(shape, 931)
+
+    def fresh(scale):
+        blk = m.TransformerBlock(c, heads, 2.66, True, "WithBias")
+        blk.load_state_dict(sd)
+        blk = blk.to(DEV)
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.mul_(scale)
+        return blk
+
+    def go(blk):
+        for p in blk.parameters():
+            p.grad = None
+        y, dx, g = run(blk, x, cot)
+        return [y, dx] + [g[k] for k in sorted(g)]
+
+    ref1, ref2 = go(fresh(1.0)), go(fresh(2.0))   # powers of two: the in-place updates below are exact
+    try:
+        ops.pw_cache_enable(32 << 20, torch.device(DEV))
+        blk = fresh(1.0)
+        go(blk)                      # registers the block's weights (still packs per call)
+        ops.pw_cache_refresh()
+        for a, b in zip(go(blk), ref1):
+            assert torch.equal(a, b)
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.mul_(2.0)
+        ops.pw_cache_refresh()       # what the trainer does after the optimizer step
+        for a, b in zip(go(blk), ref2):
+            assert torch.equal(a, b)
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.mul_(0.5)
+        ops.pw_cache_invalidate()    # weights changed without a refresh: must not use the stale images
+        for a, b in zip(go(blk), ref1):
+            assert torch.equal(a, b)
+    finally:
+        ops.pw_cache_enable(0, torch.device(DEV))
