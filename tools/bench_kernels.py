@@ -55,7 +55,8 @@ def bench_ln():
         y, mean, rstd = ops.ln_fwd(x, w, b, True)
         print(f"ln_fwd C={C} {H}x{W}: {us:8.1f} us {2 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
         dw, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-        us = timeit(lambda: ops.ln_bwd(x, x, w, mean, rstd, x, True, dw, db, False))
+        dy, dres = torch.randn_like(x), torch.randn_like(x)   # distinct tensors: three reads + one write of real traffic
+        us = timeit(lambda: ops.ln_bwd(dy, x, w, mean, rstd, dres, True, dw, db, False))
         print(f"ln_bwd C={C} {H}x{W}: {us:8.1f} us {4 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
 
 
