@@ -443,6 +443,7 @@ static bool gram_stream_ok(const mi_gram_desc* d) {
   // output (48x48 q k^T, the 144/254/127 x 48 weight gradients: 1.1-1.7x); with 96-wide or many tiles the operand
   // re-reads and 1-wave occupancy lose to the LDS-staged 128x128 tiles (0.6-0.85x).
   const GramSPlan g = gram_splan(d);
+  if (getenv("MI_GRAM_STREAM_ALL")) return true;   // A/B switch
   return g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4 && d->n >= 4096;
 }
 

@@ -652,7 +652,14 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   if (k.vec_ok && dma) {
     if (pl.tm == 128) MI_TRY((pw_launch_dma<T, 2>(q, grid, st)));
     else MI_TRY((pw_launch_dma<T, 1>(q, grid, st)));
-  } else if (pl.tm == 128 && std::is_same<T, bf16>::value && !getenv("MI_PW_SMALL_TILE")) {
+  } else if (pl.tm == 128 && std::is_same<T, bf16>::value && getenv("MI_PW_BIG_TILE")) {
+    // Opt-in.  Measured with operands beyond the 256 MB Infinity Cache (bs 32; profiles/r01_v_pw_*bs32*.log):
+    //  - this 128 x 128 tile (also as a persistent, cross-tile pipelined variant) LOSES 10-25% to the 64-pixel tiles
+    //    (2-3 resident workgroups per CU instead of 5); it had won 5-12% at bs 8, where everything sat in the cache;
+    //  - two chunks of prefetch in the 64-pixel kernel: 3-10% slower (registers cost a resident workgroup);
+    //  - an XCD-aware tile map that runs the m-tiles of one pixel tile together on one L2 (X fetched from HBM once):
+    //    15-35% SLOWER - concurrent workgroups then touch 4x more channel rows over 4x narrower pixel spans, and the
+    //    DRAM page locality lost costs more than the X re-reads saved.
     dim3 bgrid(cdiv(k.n, PWB_TN), pl.m_tiles, grid.z);   // (fp32 would need 70 KB of static LDS: it keeps the 64-pixel tiles)
     hipLaunchKernelGGL((pw_gemm_big_kernel<bf16>), bgrid, block, 0, st, q);
   } else {

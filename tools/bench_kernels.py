@@ -25,7 +25,7 @@ def timeit(fn, iters=20):
 
 def bench_pw():
     from image_restoration_amd import ops
-    B = 8
+    B = int(os.environ.get("BK_BATCH", "8"))
     shapes = [  # (M, K, H, W, transposed, residual)
         (144, 48, 256, 256, False, False), (48, 48, 256, 256, False, True), (254, 48, 256, 256, False, False),
         (48, 127, 256, 256, False, True), (48, 144, 256, 256, True, False), (127, 48, 256, 256, True, False),
@@ -83,7 +83,7 @@ def bench_gram():
     for (ma, mb, H, W, g, sb) in [(48, 48, 256, 256, 1, False), (96, 96, 256, 256, 1, False), (144, 48, 256, 256, 1, True),
                                   (254, 48, 256, 256, 1, True), (510, 96, 256, 256, 1, True), (48, 127, 256, 256, 1, True),
                                   (48, 48, 128, 128, 2, False), (1020, 192, 64, 64, 1, True)]:
-        B = 8
+        B = int(os.environ.get("BK_BATCH", "8"))   # 32: operands exceed the 256 MB Infinity Cache, like in the real step
         a = torch.randn(B, ma * g, H, W, device="cuda").bfloat16()
         b = torch.randn(B, mb * g, H, W, device="cuda").bfloat16()
         us = timeit(lambda: ops.gram(a, b, g, sb))
