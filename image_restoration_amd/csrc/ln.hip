@@ -2,11 +2,36 @@
 // stride N = H*W, so lanes map to consecutive pixels (coalesced) and the 8 waves of a
 // workgroup split the channels; per-pixel partial sums cross waves through LDS.
 // HBM-bound: reads x once (held in registers for the two-pass variance), writes y once.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mi {
 
 constexpr float LN_EPS = 1e-5f;
+
+// A lane's VEC pixels of one channel exactly as loaded: bf16 x 2 is ONE register (two floats after conversion), so
+// values that must survive between sweeps are kept raw and converted again where they are used.
+template <typename T, int VEC> struct LnRaw;
+template <> struct LnRaw<bf16, 2> {
+  using V = unsigned int;
+  static __device__ __forceinline__ V ld(const bf16* p) { return *reinterpret_cast<const unsigned int*>(p); }
+  static __device__ __forceinline__ V zero() { return 0u; }
+  static __device__ __forceinline__ void ex(V v, float* o) { o[0] = bf16_bits_to_f32(v & 0xffffu); o[1] = bf16_bits_to_f32(v >> 16); }
+};
+template <> struct LnRaw<float, 1> {
+  using V = float;
+  static __device__ __forceinline__ V ld(const float* p) { return *p; }
+  static __device__ __forceinline__ V zero() { return 0.f; }
+  static __device__ __forceinline__ void ex(V v, float* o) { o[0] = v; }
+};
+// the same conversion behind an opaque move, so that the compiler converts again at the point of use instead of keeping
+// the floats of the first conversion alive (which would undo the point of holding the values raw)
+template <typename RW> __device__ __forceinline__ void ln_ex_again(typename RW::V v, float* o) {
+  asm volatile("" : "+v"(v));
+  RW::ex(v, o);
+}
+
 
 template <typename T, int LN_WAVES, int CPT, int VEC, bool WITH_BIAS>
 __global__ __launch_bounds__(64 * LN_WAVES) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -227,9 +252,213 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const T* __restri
   }
 }
 
+// ---- wave-owned form (C <= 384): no barrier for C <= 96, one or two for wider C --------------------------------------------
+// A WAVE owns 64 x VEC pixels for up to CB = 96 channels: a lane keeps its pixels of every channel RAW in registers (one
+// register per bf16 pair; 2 CB of them in backward), so the channel reduction is an in-thread loop.  All row loads of a
+// tile - 256 bytes each, 12-49 KB per wave - are in flight together.  WS = 1: the four waves of a workgroup are unrelated
+// tiles (no LDS, no barrier).  WS = 2 / 4 (C <= 192 / 384): WS waves share a tile, each owning a 96-channel slice, and
+// exchange their per-pixel partial sums through LDS (one barrier per statistic).
+template <typename T, int CB, int VEC, bool WITH_BIAS, int WS>
+__global__ __launch_bounds__(256) void ln_fwd_wave_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, T* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          int C, int64_t N) {
+  using RW = LnRaw<T, VEC>;
+  constexpr int TILE = 64 * VEC;
+  __shared__ float red[WS > 1 ? 4 : 1][WS > 1 ? TILE : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);   // wave-uniform, and the compiler may know it (scalar addressing)
+  const int grp = wvu / WS, c0 = (wvu % WS) * CB;        // tile within the workgroup, first channel of this wave's slice
+  const int64_t n = ((int64_t)blockIdx.x * (4 / WS) + grp) * TILE + lane * VEC;
+  const bool valid = n < N;                               // whole lanes (N % VEC == 0)
+  if (WS == 1 && !valid) return;
+  const int64_t boff = (int64_t)blockIdx.y * C * N;
+  const T* xb = x + boff;
+  T* yb = y + boff;
+  const unsigned N32 = (unsigned)N, n32 = (unsigned)n;
+  typename RW::V raw[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) raw[c] = (c0 + c < C && valid) ? RW::ld(xb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();
+  float s[VEC], mu[VEC], rs[VEC];
+  auto across = [&](float* v) {   // sum over the WS slices of the tile (no-op for WS = 1)
+    if (WS > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[wv][lane * VEC + j] = v[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) t += red[grp * WS + k][lane * VEC + j];
+        v[j] = t;
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    float v[VEC];
+    RW::ex(raw[c], v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] += v[j];   // channels >= C are zeros
+  }
+  across(s);
+  const float invC = 1.0f / (float)C;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { mu[j] = s[j] * invC; s[j] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    if (c0 + c < C) {
+      float v[VEC];
+      ln_ex_again<RW>(raw[c], v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float d = v[j] - mu[j]; s[j] += d * d; }
+    }
+  }
+  across(s);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) rs[j] = 1.0f / sqrtf(s[j] * invC + LN_EPS);
+  if (!valid) return;
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    if (c0 + c < C) {
+      const float wc = w[c0 + c], bc = WITH_BIAS ? b[c0 + c] : 0.f;
+      float v[VEC], o[VEC];
+      ln_ex_again<RW>(raw[c], v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = WITH_BIAS ? (v[j] - mu[j]) * rs[j] * wc + bc : v[j] * rs[j] * wc;
+      Vec<T, VEC>::st(yb + ((unsigned)(c0 + c) * N32 + n32), o);
+    }
+  }
+  if (mean_out && c0 == 0) {
+    const int64_t so = (int64_t)blockIdx.y * N + n;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mean_out[so + j] = mu[j]; rstd_out[so + j] = rs[j]; }
+  }
+}
+
+// backward, same ownership; one partial row [2C] per tile: part[(b * tiles + tile)][c | C + c]
+template <typename T, int CB, int VEC, bool WITH_BIAS, int WS, bool WGRAD>
+__global__ __launch_bounds__(256) void ln_bwd_wave_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                          T* __restrict__ dx, float* __restrict__ part, int C, int64_t N,
+                                                          int tiles) {
+  using RW = LnRaw<T, VEC>;
+  constexpr int TILE = 64 * VEC;
+  __shared__ float red[WS > 1 ? 4 : 1][2][WS > 1 ? TILE : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const int grp = wvu / WS, c0 = (wvu % WS) * CB;
+  const int tile = blockIdx.x * (4 / WS) + grp;
+  const bool tile_ok = tile < tiles;                      // wave-uniform
+  if (WS == 1 && !tile_ok) return;
+  const int64_t n = (int64_t)tile * TILE + lane * VEC;
+  const bool valid = tile_ok && n < N;
+  const int64_t boff = (int64_t)blockIdx.y * C * N;
+  const T* dyb = dy + boff;
+  const T* xb = x + boff;
+  const T* rb = dres ? dres + boff : nullptr;
+  T* dxb = dx + boff;
+  const unsigned N32 = (unsigned)N, n32 = (unsigned)n;
+  typename RW::V graw[CB], xraw[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const bool in = c0 + c < C && valid;
+    graw[c] = in ? RW::ld(dyb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();
+    xraw[c] = in ? RW::ld(xb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();
+  }
+  float mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = valid ? mean[(int64_t)blockIdx.y * N + n + j] : 0.f;
+    rs[j] = valid ? rstd[(int64_t)blockIdx.y * N + n + j] : 0.f;
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  float* prow = part + ((int64_t)blockIdx.y * tiles + (tile_ok ? tile : 0)) * (2 * C);
+  // sweep 1: per-pixel channel sums, and the per-channel weight / bias gradient partials of this tile
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    if (c0 + c < C) {
+      const float wc = w[c0 + c];
+      float gi[VEC], xi[VEC];
+      RW::ex(graw[c], gi); RW::ex(xraw[c], xi);
+      float aw = 0.f, ab = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gw = gi[j] * wc;
+        if (WITH_BIAS) {
+          const float xh = (xi[j] - mu[j]) * rs[j];
+          s1[j] += gw; s2[j] += gw * xh;
+          aw += gi[j] * xh; ab += gi[j];
+        } else {
+          s2[j] += gw * xi[j];
+          aw += gi[j] * xi[j] * rs[j];
+        }
+      }
+      if (WGRAD) {
+        aw = wave_sum(aw);
+        if (WITH_BIAS) ab = wave_sum(ab);
+        if (lane == 0 && tile_ok) { prow[c0 + c] = aw; prow[C + c0 + c] = ab; }
+      }
+    }
+  }
+  if (WS > 1) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[wv][0][lane * VEC + j] = s1[j]; red[wv][1][lane * VEC + j] = s2[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WS; ++k) { t1 += red[grp * WS + k][0][lane * VEC + j]; t2 += red[grp * WS + k][1][lane * VEC + j]; }
+      s1[j] = t1; s2[j] = t2;
+    }
+  }
+  if (!valid) return;
+  const float invC = 1.0f / (float)C;
+  float m1[VEC], m2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { m1[j] = s1[j] * invC; m2[j] = s2[j] * invC; }
+  // sweep 2: dx (+ the residual branch's gradient)
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    if (c0 + c < C) {
+      const float wc = w[c0 + c];
+      float gi[VEC], xi[VEC], o[VEC];
+      ln_ex_again<RW>(graw[c], gi); ln_ex_again<RW>(xraw[c], xi);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gw = gi[j] * wc;
+        if (WITH_BIAS) o[j] = rs[j] * (gw - m1[j] - (xi[j] - mu[j]) * rs[j] * m2[j]);
+        else o[j] = rs[j] * gw - rs[j] * rs[j] * rs[j] * (xi[j] - mu[j]) * m2[j];
+      }
+      if (rb) {
+        float r[VEC];
+        Vec<T, VEC>::ld(rb + ((unsigned)(c0 + c) * N32 + n32), r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += r[j];
+      }
+      Vec<T, VEC>::st(dxb + ((unsigned)(c0 + c) * N32 + n32), o);
+    }
+  }
+}
+
 // Shape -> (waves W, channels per thread CPT, pixels per lane VEC).  W*CPT >= C.  Measured on MI355X: wider per-lane
 // vectors (8 or 16 bytes) LOSE here (ln_fwd C=48: 27 -> 40 us) because the extra registers cut the resident
 // workgroups per CU, and these kernels live on bytes in flight; so bf16 keeps 2 pixels (one dword) per lane.
+// which shapes take the wave-owned kernels: MI_LN_FORM=wave|block forces one form for A/B runs
+// Measured with operands beyond the Infinity Cache (bs 32, profiles/r01_w_ln_forms_bs32.log): forward, wave-owned wins
+// 1.2-1.75x up to C = 192 (4.7-5.1 TB/s against 2.7-2.9); backward, it wins 1.5x for 96 < C <= 192 and loses 1.35x
+// for C <= 96, where 2C raw registers leave two waves per SIMD (also tried there: d gamma / d beta split off into a
+// row-streaming pass - slower still).
+static bool ln_wave_form(int C, bool bwd) {
+  if (C > 384) return false;
+  if (const char* e = getenv("MI_LN_FORM")) return e[0] == 'w';
+  return bwd ? (C > 96 && C <= 192) : C <= 192;
+}
 struct LnCfg { int waves, cpt, vec; };
 static LnCfg ln_cfg(int C, bool bwd, bool f32) {
   const int v = f32 ? 1 : 2;
@@ -258,6 +487,18 @@ static int ln_fwd_dispatch(const T* x, const float* w, const float* b, T* y, flo
   if (!ln_aligned(cf.vec, sizeof(T), N, x, y, nullptr, nullptr)) cf.vec = 1;
   dim3 grid(cdiv(N, 64 * cf.vec), B);
   ProfScope ps(st, K_LN_FWD, 2.0 * B * C * N * sizeof(T) + (mean ? 8.0 * B * N : 0.0), 8.0 * B * C * N);
+  constexpr int WVEC = F32 ? 1 : 2;
+  if (ln_wave_form(C, false) && cf.vec == WVEC) {   // wave-owned form
+    const int ws = C <= 96 ? 1 : (C <= 192 ? 2 : 4);
+    dim3 wgrid(cdiv(N, 64 * WVEC * (4 / ws)), B);
+#define LN_FWDW_CASE(CB, WS_) \
+    hipLaunchKernelGGL((ln_fwd_wave_kernel<T, CB, WVEC, WB, WS_>), wgrid, dim3(256), 0, st, x, w, b, y, mean, rstd, C, N)
+    if (C <= 16) LN_FWDW_CASE(16, 1); else if (C <= 48) LN_FWDW_CASE(48, 1); else if (C <= 96) LN_FWDW_CASE(96, 1);
+    else if (C <= 192) LN_FWDW_CASE(96, 2); else LN_FWDW_CASE(96, 4);
+#undef LN_FWDW_CASE
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
 #define LN_FWD_CASE(WV, CPT, VEC)                                                                                   \
   if (cf.waves == WV && cf.cpt == CPT && cf.vec == VEC)                                                                 \
     hipLaunchKernelGGL((ln_fwd_kernel<T, WV, CPT, VEC, WB>), grid, dim3(64 * WV), 0, st, x, w, b, y, mean, rstd, C, N)
@@ -282,6 +523,22 @@ static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float*
   *rows_out = gx * B;
   dim3 grid(gx, B);
   ProfScope ps(st, K_LN_BWD, (dres ? 4.0 : 3.0) * B * C * N * sizeof(T) + 8.0 * B * N, 16.0 * B * C * N);
+  constexpr int WVEC = F32 ? 1 : 2;
+  if (ln_wave_form(C, true) && cf.vec == WVEC && ln_aligned(WVEC, sizeof(T), N, dy, x, dres, dx)) {
+    // wave-owned form; same partial-row layout (one row per 64*VEC-pixel tile)
+    const int ws = C <= 96 ? 1 : (C <= 192 ? 2 : 4);
+    const int wtiles = cdiv(N, 64 * WVEC);
+    *rows_out = wtiles * B;
+    dim3 wgrid(cdiv(wtiles, 4 / ws), B);
+#define LN_BWDW_CASE(CB, WS_, WG_) \
+    hipLaunchKernelGGL((ln_bwd_wave_kernel<T, CB, WVEC, WB, WS_, WG_>), wgrid, dim3(256), 0, st, dy, x, w, mean, rstd, dres, \
+                       dx, part, C, N, wtiles)
+    if (C <= 16) LN_BWDW_CASE(16, 1, true); else if (C <= 48) LN_BWDW_CASE(48, 1, true);
+    else if (C <= 96) LN_BWDW_CASE(96, 1, true); else if (C <= 192) LN_BWDW_CASE(96, 2, true); else LN_BWDW_CASE(96, 4, true);
+#undef LN_BWDW_CASE
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
 #define LN_BWD_CASE(WV, CPT, VEC)                                                                                     \
   if (cf.waves == WV && cf.cpt == CPT && cf.vec == VEC)                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<T, WV, CPT, VEC, WB, (CPT >= 24)>), grid, dim3(64 * WV), 0, st, dy, x, w, mean, rstd, \

@@ -48,7 +48,7 @@ def bench_pw():
 def bench_ln():
     from image_restoration_amd import ops
     for (C, H, W) in [(48, 256, 256), (96, 256, 256), (96, 128, 128), (192, 64, 64), (384, 32, 32)]:
-        B = 8
+        B = int(os.environ.get("BK_BATCH", "8"))
         x = torch.randn(B, C, H, W, device="cuda").bfloat16()
         w, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
         us = timeit(lambda: ops.ln_fwd(x, w, b, True))
