@@ -340,19 +340,19 @@ __global__ __launch_bounds__(256) void ln_fwd_wave_kernel(const T* __restrict__ 
 }
 
 // backward, same ownership; one partial row [2C] per tile: part[(b * tiles + tile)][c | C + c]
-template <typename T, int CB, int VEC, bool WITH_BIAS, int WS, bool WGRAD>
-__global__ __launch_bounds__(256) void ln_bwd_wave_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int CB, int VEC, bool WITH_BIAS, int WS, bool WGRAD, bool RPRE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_wave_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const T* __restrict__ dres,
                                                           T* __restrict__ dx, float* __restrict__ part, int C, int64_t N,
                                                           int tiles) {
   using RW = LnRaw<T, VEC>;
   constexpr int TILE = 64 * VEC;
-  __shared__ float red[WS > 1 ? 4 : 1][2][WS > 1 ? TILE : 1];
+  __shared__ float red[WS > 1 ? NW : 1][2][WS > 1 ? TILE : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
   const int grp = wvu / WS, c0 = (wvu % WS) * CB;
-  const int tile = blockIdx.x * (4 / WS) + grp;
+  const int tile = blockIdx.x * (NW / WS) + grp;
   const bool tile_ok = tile < tiles;                      // wave-uniform
   if (WS == 1 && !tile_ok) return;
   const int64_t n = (int64_t)tile * TILE + lane * VEC;
@@ -363,12 +363,13 @@ __global__ __launch_bounds__(256) void ln_bwd_wave_kernel(const T* __restrict__ 
   const T* rb = dres ? dres + boff : nullptr;
   T* dxb = dx + boff;
   const unsigned N32 = (unsigned)N, n32 = (unsigned)n;
-  typename RW::V graw[CB], xraw[CB];
+  typename RW::V graw[CB], xraw[CB], rraw[RPRE ? CB : 1];
 #pragma unroll
   for (int c = 0; c < CB; ++c) {
     const bool in = c0 + c < C && valid;
     graw[c] = in ? RW::ld(dyb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();
     xraw[c] = in ? RW::ld(xb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();
+    if (RPRE) rraw[c] = (in && rb) ? RW::ld(rb + ((unsigned)(c0 + c) * N32 + n32)) : RW::zero();   // residual gradient, in flight with the rest
   }
   float mu[VEC], rs[VEC], s1[VEC], s2[VEC];
 #pragma unroll
@@ -435,7 +436,12 @@ __global__ __launch_bounds__(256) void ln_bwd_wave_kernel(const T* __restrict__ 
         if (WITH_BIAS) o[j] = rs[j] * (gw - m1[j] - (xi[j] - mu[j]) * rs[j] * m2[j]);
         else o[j] = rs[j] * gw - rs[j] * rs[j] * rs[j] * (xi[j] - mu[j]) * m2[j];
       }
-      if (rb) {
+      if (RPRE) {
+        float r[VEC];
+        RW::ex(rraw[c], r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += r[j];     // zeros when there is no residual branch
+      } else if (rb) {
         float r[VEC];
         Vec<T, VEC>::ld(rb + ((unsigned)(c0 + c) * N32 + n32), r);
 #pragma unroll
@@ -451,13 +457,11 @@ __global__ __launch_bounds__(256) void ln_bwd_wave_kernel(const T* __restrict__ 
 // workgroups per CU, and these kernels live on bytes in flight; so bf16 keeps 2 pixels (one dword) per lane.
 // which shapes take the wave-owned kernels: MI_LN_FORM=wave|block forces one form for A/B runs
 // Measured with operands beyond the Infinity Cache (bs 32, profiles/r01_w_ln_forms_bs32.log): forward, wave-owned wins
-// 1.2-1.75x up to C = 192 (4.7-5.1 TB/s against 2.7-2.9); backward, it wins 1.5x for 96 < C <= 192 and loses 1.35x
-// for C <= 96, where 2C raw registers leave two waves per SIMD (also tried there: d gamma / d beta split off into a
-// row-streaming pass - slower still).
+// 1.2-1.75x up to C = 192 (4.7-5.1 TB/s against 2.7-2.9); backward with 24-channel slices wins 1.05-2.3x up to C = 192.
 static bool ln_wave_form(int C, bool bwd) {
   if (C > 384) return false;
   if (const char* e = getenv("MI_LN_FORM")) return e[0] == 'w';
-  return bwd ? (C > 96 && C <= 192) : C <= 192;
+  return bwd ? C <= (getenv("MI_LN_BWD384") ? 384 : 192) : C <= 192;
 }
 struct LnCfg { int waves, cpt, vec; };
 static LnCfg ln_cfg(int C, bool bwd, bool f32) {
@@ -526,15 +530,15 @@ static int ln_bwd_dispatch(const T* dy, const T* x, const float* w, const float*
   constexpr int WVEC = F32 ? 1 : 2;
   if (ln_wave_form(C, true) && cf.vec == WVEC && ln_aligned(WVEC, sizeof(T), N, dy, x, dres, dx)) {
     // wave-owned form; same partial-row layout (one row per 64*VEC-pixel tile)
-    const int ws = C <= 96 ? 1 : (C <= 192 ? 2 : 4);
     const int wtiles = cdiv(N, 64 * WVEC);
     *rows_out = wtiles * B;
-    dim3 wgrid(cdiv(wtiles, 4 / ws), B);
-#define LN_BWDW_CASE(CB, WS_, WG_) \
-    hipLaunchKernelGGL((ln_bwd_wave_kernel<T, CB, WVEC, WB, WS_, WG_>), wgrid, dim3(256), 0, st, dy, x, w, mean, rstd, dres, \
-                       dx, part, C, N, wtiles)
-    if (C <= 16) LN_BWDW_CASE(16, 1, true); else if (C <= 48) LN_BWDW_CASE(48, 1, true);
-    else if (C <= 96) LN_BWDW_CASE(96, 1, true); else if (C <= 192) LN_BWDW_CASE(96, 2, true); else LN_BWDW_CASE(96, 4, true);
+#define LN_BWDW_CASE(CB, WS_, NW_)                                                                                      \
+    hipLaunchKernelGGL((ln_bwd_wave_kernel<T, CB, WVEC, WB, WS_, true, true, NW_>), dim3(cdiv(wtiles, NW_ / WS_), B),       \
+                       dim3(64 * NW_), 0, st, dy, x, w, mean, rstd, dres, dx, part, C, N, wtiles)
+    // 24-channel slices: C / 24 waves share a 128-pixel tile (measured: 96-channel slices 1.35x slower than the block
+    // kernel at C = 96, 48-channel 1.28x faster, 24-channel 1.63x faster; profiles/r01_w_ln_forms_bs32.log)
+    if (C <= 16) LN_BWDW_CASE(16, 1, 4); else if (C <= 24) LN_BWDW_CASE(24, 1, 4); else if (C <= 48) LN_BWDW_CASE(24, 2, 4);
+    else if (C <= 96) LN_BWDW_CASE(24, 4, 4); else if (C <= 192) LN_BWDW_CASE(24, 8, 8); else LN_BWDW_CASE(24, 16, 16);
 #undef LN_BWDW_CASE
     MI_LAUNCH_CHECK();
     return MI_OK;
