@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/rp_final
 mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --graph 0 --no-cpu-baseline --no-roofline"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
