@@ -444,7 +444,12 @@ static bool gram_stream_ok(const mi_gram_desc* d) {
   // re-reads and 1-wave occupancy lose to the LDS-staged 128x128 tiles (0.6-0.85x).
   const GramSPlan g = gram_splan(d);
   if (getenv("MI_GRAM_STREAM_ALL")) return true;   // A/B switch
-  return g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4 && d->n >= 4096;
+  if (d->n < 4096) return false;
+  if (g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4) return true;
+  // ... and where the 128 x 128 LDS tiles would be mostly padding (288 x 96 fills 56% of 3 x 1 tiles: streaming 1.27x
+  // faster at bs 32; 96 x 255 and 510 x 96 fill 75% and stay on the LDS kernel; profiles/r01_y_gram_bs32.log)
+  const double lds_fill = (double)d->ma * d->mb / ((double)cdiv(d->ma, 128) * 128 * cdiv(d->mb, 128) * 128);
+  return (d->ma > 64 || d->mb > 64) && lds_fill < 0.6;
 }
 
 static int gram_check(const mi_gram_desc* d) {

@@ -82,7 +82,8 @@ def bench_gram():
     from image_restoration_amd import ops
     for (ma, mb, H, W, g, sb) in [(48, 48, 256, 256, 1, False), (96, 96, 256, 256, 1, False), (144, 48, 256, 256, 1, True),
                                   (254, 48, 256, 256, 1, True), (510, 96, 256, 256, 1, True), (48, 127, 256, 256, 1, True),
-                                  (48, 48, 128, 128, 2, False), (1020, 192, 64, 64, 1, True)]:
+                                  (48, 48, 128, 128, 2, False), (1020, 192, 64, 64, 1, True),
+                                  (288, 96, 256, 256, 1, True), (96, 255, 256, 256, 1, True), (288, 96, 128, 128, 1, True)]:
         B = int(os.environ.get("BK_BATCH", "8"))   # 32: operands exceed the 256 MB Infinity Cache, like in the real step
         a = torch.randn(B, ma * g, H, W, device="cuda").bfloat16()
         b = torch.randn(B, mb * g, H, W, device="cuda").bfloat16()
