@@ -94,6 +94,9 @@ SIGNATURES = {
                                 vp, vp]),
     "mi_dwconv_gate_bwd": (C.c_int, [vp, vp, vp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, vp, vp]),
+    "mi_dwconv_gate_recompute_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mi_dwconv_gate_bwd_recompute": (C.c_int, [vp, vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, vp, vp]),
     "mi_pw_gemm_workspace": (C.c_size_t, [C.POINTER(PwDesc)]),
     "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp, vp]),
     "mi_pw_cache_enable": (C.c_int, [vp, C.c_size_t]),

@@ -700,6 +700,39 @@ static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, co
   return MI_OK;
 }
 
+extern "C" int mi_dwconv_gate_recompute_ok(int H, int W, int ks) { return dws_eligible(H, W, ks) ? 1 : 0; }
+
+extern "C" int mi_dwconv_gate_bwd_recompute(const void* dg, const void* x, const float* w, const float* bias, void* dx,
+                                            float* dwg, float* dbg, int B, int C2, int H, int W, int ks, int accumulate,
+                                            int dtype, void* ws, void* stream) {
+  MI_CHECK_ARG(dg && x && w, "dwconv_gate_bwd_recompute: null pointer");
+  MI_CHECK_ARG(C2 % 2 == 0, "dwconv_gate_bwd_recompute: channel count %d must be even", C2);
+  MI_TRY(check_common("dwconv_gate_bwd_recompute", B, C2, H, W, ks, dtype));
+  MI_CHECK_ARG(dx || dwg, "dwconv_gate_bwd_recompute: nothing to compute");
+  MI_CHECK_ARG(!dwg || ws, "dwconv_gate_bwd_recompute: weight gradient needs a workspace");
+  MI_CHECK_ARG(dws_eligible(H, W, ks) && aligned16(dg) && aligned16(x) && aligned16(dx),
+               "dwconv_gate_bwd_recompute: needs a 3x3 kernel, rows of 16..256 pixels (power of two) and 16-byte aligned "
+               "planes (mi_dwconv_gate_recompute_ok); store y and use mi_dwconv_gate_bwd otherwise");
+  hipStream_t st = (hipStream_t)stream;
+  DwArgs a{dg, x, w, bias, dx, nullptr, C2, H, W, C2 / 2, 0};
+  int rows = 0;
+  float* part = (float*)ws;
+  {
+    const double plane = (double)B * H * W * dtype_size(dtype);
+    ProfScope ps(st, dx ? K_DW_GATE_BWD_DATA : K_DW_WGRAD, (C2 / 2 + (double)C2 + (dx ? C2 : 0)) * plane,
+                 ((dx ? 2.0 : 0.0) + (dwg ? 2.0 : 0.0) + 2.0) * 9 * C2 * (double)B * H * W);
+    MI_TRY(dws_gate_bwd_recompute(a, part, B, dwg != nullptr, &rows, dtype, st));
+  }
+  if (dwg) {
+    const int64_t ld = (int64_t)C2 * 10;
+    float* tmp = part + (int64_t)rows * ld;
+    MI_TRY(launch_reduce_rows(part, dwg, rows, (int64_t)C2 * 9, ld, accumulate, 1.0f, st, tmp));
+    if (dbg) MI_TRY(launch_reduce_rows(part + (int64_t)C2 * 9, dbg, rows, C2, ld, accumulate, 1.0f, st,
+                                       tmp + (int64_t)REDUCE_GROUPS * C2 * 9));
+  }
+  return MI_OK;
+}
+
 extern "C" int mi_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float* dwg, float* dbg, int B, int C,
                              int H, int W, int ks, int accumulate, int dtype, void* ws, void* stream) {
   MI_CHECK_ARG(dy && w, "dwconv_bwd: null pointer");

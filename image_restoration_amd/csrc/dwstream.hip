@@ -343,6 +343,127 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
   }
 }
 
+// ---- GDFN gate backward WITHOUT the stored conv outputs: y1, y2 are recomputed from the conv input -----------------------
+// The fused form above reads (dg, y1, y2, x1, x2) = 5 planes per channel pair and the forward had to write y1, y2 for
+// it: 4 of the 12 plane-passes of a GDFN's depthwise stage exist only to carry y from forward to backward.  The input
+// rows x1, x2 are needed here anyway (weight gradient), so this kernel slides a 3-row window over THEM too, re-does the
+// two 3x3 stencils (72 FMAs per lane and row - the VALU is idle in these kernels) and forms d1, d2 from the result:
+// 3 planes read instead of 5, and the forward writes g only.  Rows: d(r) needs x rows r-1..r+1, dx(y) needs d rows
+// y-1..y+1, so a band [y0, yend) reads x rows y0-2 .. yend+1 and dg rows y0-1 .. yend.
+template <typename T, int LPR, bool UNI, bool WANT_DW>
+__global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* __restrict__ part, int planes, int nb,
+                                                              int band_rows) {
+  using R = Raw<T>;
+  using RV = typename R::V;
+  const Unit<LPR, UNI> u(planes, nb, band_rows);
+  const int h = a.hidden;
+  const int b = u.active ? u.plane / h : 0, j = u.active ? u.plane - b * h : 0;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int x = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const T* dgp = (const T*)a.in + ((int64_t)b * h + j) * HW + x;          // dg [B, h, H, W]
+  const T* x1p = (const T*)a.gy + ((int64_t)b * a.Cc + j) * HW + x;       // conv input [B, 2h, H, W] (passed in a.gy)
+  const T* x2p = x1p + (int64_t)h * HW;
+  float w1[9], w2[9], b1 = 0.f, b2 = 0.f;                                  // forward taps; the transposed conv reads them reversed
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { w1[i] = a.w[(int64_t)j * 9 + i]; w2[i] = a.w[(int64_t)(j + h) * 9 + i]; }
+  if (a.bias) { b1 = a.bias[j]; b2 = a.bias[j + h]; }
+  const int yend = min(u.y0 + band_rows, a.H);
+  auto ld = [&](const T* base, int y, int ymax) -> RV {
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+  };
+  float hA1[6], hB1[6], hC1[6], hA2[6], hB2[6], hC2[6];                    // x rows rho-1, rho, rho+1 of both planes
+  float p0[6], p1[6], p2[6], q0[6], q1[6], q2[6];                          // d1 / d2 rows y-1, y, y+1
+  float acc1[WANT_DW ? 10 : 1], acc2[WANT_DW ? 10 : 1];
+  if (WANT_DW) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
+  }
+  // d row rho from dg row rho and x rows rho-1 (hA), rho (hB), rho+1 (raw, becomes hC); rows outside the image give d = 0
+  auto d_row = [&](int rho, const RV& rdg, const RV& rx1, const RV& rx2, float* pd, float* qd) {
+    float v[4], dg[4], y1[4], y2[4], d1[4], d2[4];
+    R::expand(rx1, v); window_row(v, first, last, hC1);
+    R::expand(rx2, v); window_row(v, first, last, hC2);
+    stencil(w1, b1, hA1, hB1, hC1, y1);
+    stencil(w2, b2, hA2, hB2, hC2, y2);
+    R::expand(rdg, dg);                          // zero for rows outside the image / band halo limits
+    const bool inside = rho >= 0 && rho < a.H;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a1 = y1[q], a2 = y2[q];      // fp32, exactly what the forward gated (it does not store y either)
+      float cdf, pdf;
+      gelu_parts(a1, cdf, pdf);
+      d1[q] = inside ? dg[q] * a2 * (cdf + a1 * pdf) : 0.f;
+      d2[q] = inside ? dg[q] * a1 * cdf : 0.f;
+    }
+    window_row(d1, first, last, pd);
+    window_row(d2, first, last, qd);
+  };
+  auto h_shift = [&]() { copy6(hA1, hB1); copy6(hB1, hC1); copy6(hA2, hB2); copy6(hB2, hC2); };
+
+  RV cg[PFG], c1[PFG], c2[PFG];
+  {
+    float v[4];
+    const RV ra1 = ld(x1p, u.y0 - 2, yend + 1), ra2 = ld(x2p, u.y0 - 2, yend + 1);
+    const RV rb1 = ld(x1p, u.y0 - 1, yend + 1), rb2 = ld(x2p, u.y0 - 1, yend + 1);
+    const RV rc1 = ld(x1p, u.y0, yend + 1), rc2 = ld(x2p, u.y0, yend + 1);
+    const RV rd1 = ld(x1p, u.y0 + 1, yend + 1), rd2 = ld(x2p, u.y0 + 1, yend + 1);
+    const RV g0 = ld(dgp, u.y0 - 1, yend), g1 = ld(dgp, u.y0, yend);
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      cg[i] = ld(dgp, u.y0 + 1 + i, yend);
+      c1[i] = ld(x1p, u.y0 + 2 + i, yend + 1);
+      c2[i] = ld(x2p, u.y0 + 2 + i, yend + 1);
+    }
+    R::expand(ra1, v); window_row(v, first, last, hA1);
+    R::expand(ra2, v); window_row(v, first, last, hA2);
+    R::expand(rb1, v); window_row(v, first, last, hB1);
+    R::expand(rb2, v); window_row(v, first, last, hB2);
+    d_row(u.y0 - 1, g0, rc1, rc2, p0, q0); h_shift();
+    d_row(u.y0, g1, rd1, rd2, p1, q1); h_shift();
+  }
+  T* o1p = a.out ? (T*)a.out + ((int64_t)b * a.Cc + j) * HW + x : nullptr;
+  T* o2p = o1p ? o1p + (int64_t)h * HW : nullptr;
+  for (int yy = 0; yy < band_rows; yy += PFG) {
+#pragma unroll
+    for (int i = 0; i < PFG; ++i) {
+      const int y = u.y0 + yy + i;
+      const bool st = u.active && y < yend;
+      // now hA = x row y, hB = x row y+1; the raw slots hold dg row y+1 and x row y+2
+      d_row(y + 1, cg[i], c1[i], c2[i], p2, q2);
+      cg[i] = ld(dgp, y + PFG + 1, yend); c1[i] = ld(x1p, y + PFG + 2, yend + 1); c2[i] = ld(x2p, y + PFG + 2, yend + 1);
+      if (o1p) {
+        float o[4], wt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = w1[8 - k];
+        stencil(wt, 0.f, p0, p1, p2, o);
+        if (st) store4(o1p + (int64_t)y * a.W, o);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[k] = w2[8 - k];
+        stencil(wt, 0.f, q0, q1, q2, o);
+        if (st) store4(o2p + (int64_t)y * a.W, o);
+      }
+      if (WANT_DW && y < yend) {
+        wgrad_row(&hA1[1], p0, p1, p2, acc1);    // x row y, own 4 pixels
+        wgrad_row(&hA2[1], q0, q1, q2, acc2);
+      }
+      h_shift();
+      copy6(p0, p1); copy6(p1, p2); copy6(q0, q1); copy6(q1, q2);
+    }
+  }
+  if (WANT_DW) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { acc1[i] = group_sum<LPR>(acc1[i]); acc2[i] = group_sum<LPR>(acc2[i]); }
+    if (u.active && u.lx == 0) {
+      float* prow = part + ((int64_t)b * nb + u.band) * ((int64_t)a.Cc * 10);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { prow[(int64_t)j * 9 + i] = acc1[i]; prow[(int64_t)(j + h) * 9 + i] = acc2[i]; }
+      prow[(int64_t)a.Cc * 9 + j] = acc1[9];
+      prow[(int64_t)a.Cc * 9 + j + h] = acc2[9];
+    }
+  }
+}
+
 // rows per band: tall bands amortise the two halo rows; short ones keep >= ~8 waves per SIMD on small launches
 static int pick_band(int H, int64_t planes, int lpr) {
   const int G = 64 / lpr;
@@ -434,6 +555,26 @@ int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want
   })
   if (dtype == MI_F32) { DWS_GB(float); } else { DWS_GB(bf16); }
 #undef DWS_GB
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+
+// gate backward with y recomputed from the conv input: a.in = dg, a.gy = conv input x [B, 2h, H, W], a.bias = conv bias
+int dws_gate_bwd_recompute(const DwArgs& a, float* part, int B, bool want_dw, int* rows_out, int dtype, hipStream_t st) {
+  const int64_t planes = (int64_t)B * a.hidden;
+  const Plan p = make_plan(a.H, a.W, planes);
+  *rows_out = p.nb * B;
+  dim3 grid(p.blocks), block(256);
+#define DWS_GBR(T_)                                                                                                       \
+  DWS_LPR_SWITCH(a.W, {                                                                                                   \
+    if (want_dw) hipLaunchKernelGGL((dws_gate_bwd_rc_kernel<T_, LPR, UNI, true>), grid, block, 0, st, a, part, (int)planes, \
+                                    p.nb, p.band);                                                                        \
+    else hipLaunchKernelGGL((dws_gate_bwd_rc_kernel<T_, LPR, UNI, false>), grid, block, 0, st, a, part, (int)planes, p.nb,  \
+                            p.band);                                                                                      \
+  })
+  if (dtype == MI_F32) { DWS_GBR(float); } else { DWS_GBR(bf16); }
+#undef DWS_GBR
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -40,4 +40,6 @@ int dws_fwd(const DwArgs& a, int B, bool gate, bool flip, int dtype, hipStream_t
 int dws_bwd(const DwArgs& dya, const void* xin, float* part, int B, bool want_dx, int* rows_out, int dtype, hipStream_t st);
 int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want_dw, int* rows_out, int dtype,
                  hipStream_t st);
+// same, with the conv outputs recomputed from the conv input: a.in = dg, a.gy = conv input x, a.bias = conv bias
+int dws_gate_bwd_recompute(const DwArgs& a, float* part, int B, bool want_dw, int* rows_out, int dtype, hipStream_t st);
 }  // namespace mi

@@ -2,6 +2,8 @@
 // (FeedForward.forward/backward, Restormer.py:76-93) as fixed sequences of the three kernel
 // archetypes (pointwise MFMA GEMM, pixel-axis Gram, depthwise stencil) plus the c x c glue.
 // Host code only: carves the caller's saved/workspace blobs and enqueues kernels on the given stream.
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace mi {
@@ -272,13 +274,21 @@ static int xmdta_check(const mi_xmdta_shape* s) {
 }
 
 // ------------------------------------------------------------------ GDFN
+// Saved for backward: the conv input h0 (2h planes), the conv output h1 (2h planes) and the gate output g (h planes).
+// MI_GDFN_RECOMPUTE=1 drops h1 (40% of the GDFN's saved bytes) and lets backward recompute it from h0
+// (mi_dwconv_gate_bwd_recompute).  It is NOT the default: beyond the Infinity Cache the forward gains 173 us per launch
+// from not writing y (539 -> 366 us, C=254 at 256^2, bs 32) but the recomputing backward loses 242 us (732 -> 975 us): with
+// two more 3x3 stencils per row it is VALU-bound at 2.7 TB/s (profiles/r01_z_gdfn_recompute_bs32.log).
 struct GdfnSaved { void* h0; void* h1; void* g; size_t bytes; };
+static bool gdfn_recompute(const mi_gdfn_shape* s) {
+  return getenv("MI_GDFN_RECOMPUTE") && mi_dwconv_gate_recompute_ok(s->H, s->W, s->ks) != 0;
+}
 static GdfnSaved gdfn_saved_layout(const mi_gdfn_shape* s, void* base) {
   const size_t N = (size_t)s->H * s->W, B = s->B, h = s->hidden;
   Carver cv(base);
   GdfnSaved r;
   r.h0 = cv.take(tbytes(B * 2 * h * N, s->dtype));
-  r.h1 = cv.take(tbytes(B * 2 * h * N, s->dtype));
+  r.h1 = gdfn_recompute(s) ? nullptr : cv.take(tbytes(B * 2 * h * N, s->dtype));
   r.g = cv.take(tbytes(B * h * N, s->dtype));
   r.bytes = cv.off;
   return r;
@@ -454,8 +464,8 @@ extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   GdfnSaved sv = saved ? gdfn_saved_layout(s, saved) : w.inf;
   mi_pw_desc d1 = conv1x1(x, C, p->in_w, false, C, p->in_b, nullptr, sv.h0, 2 * h, B, N, dt);       // Restormer.py:89
   MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
-  MI_TRY(mi_dwconv_gate_fwd(sv.h0, p->dw_w, p->dw_b, saved ? sv.h1 : nullptr, sv.g, B, 2 * h, s->H, s->W, s->ks, dt,
-                            stream));                                                                // :90-91
+  MI_TRY(mi_dwconv_gate_fwd(sv.h0, p->dw_w, p->dw_b, (saved && !gdfn_recompute(s)) ? sv.h1 : nullptr, sv.g, B, 2 * h, s->H,
+                            s->W, s->ks, dt, stream));                                               // :90-91
   mi_pw_desc d2 = conv1x1(sv.g, h, p->out_w, false, h, p->out_b, residual, out, C, B, N, dt);       // :92
   MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
@@ -476,8 +486,12 @@ extern "C" int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   MI_TRY(mi_gram(&g1, w.gram_ws, stream));
   mi_pw_desc d1 = conv1x1(dout, C, p->out_w, true, h, nullptr, nullptr, w.dg, h, B, N, dt);
   MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
-  MI_TRY(mi_dwconv_gate_bwd(w.dg, sv.h1, sv.h0, p->dw_w, w.dh0, gr->dw_w, gr->dw_b, B, 2 * h, s->H, s->W, s->ks, acc, dt,
-                            w.dw_ws, stream));
+  if (gdfn_recompute(s))
+    MI_TRY(mi_dwconv_gate_bwd_recompute(w.dg, sv.h0, p->dw_w, p->dw_b, w.dh0, gr->dw_w, gr->dw_b, B, 2 * h, s->H, s->W, s->ks,
+                                        acc, dt, w.dw_ws, stream));
+  else
+    MI_TRY(mi_dwconv_gate_bwd(w.dg, sv.h1, sv.h0, p->dw_w, w.dh0, gr->dw_w, gr->dw_b, B, 2 * h, s->H, s->W, s->ks, acc, dt,
+                              w.dw_ws, stream));
   mi_gram_desc g2 = wgrad_gram(w.dh0, 2 * h, x, C, B, N, dt, gr->in_w, acc);
   MI_TRY(mi_gram(&g2, w.gram_ws, stream));
   if (gr->in_b) MI_TRY(launch_chan_sum(w.dh0, gr->in_b, B, 2 * h, N, dt, acc, w.cs_ws, st));

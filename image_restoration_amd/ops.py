@@ -127,6 +127,24 @@ def dwconv_gate_bwd(dg: Tensor, y: Tensor, x: Tensor, w: Tensor, has_bias: bool)
 
 
 # ----------------------------------------------------------------------------- pointwise GEMM / Gram
+def dwconv_gate_recompute_ok(H: int, W: int, ks: int) -> bool:
+    return bool(L.lib().mi_dwconv_gate_recompute_ok(H, W, ks))
+
+
+def dwconv_gate_bwd_recompute(dg: Tensor, x: Tensor, w: Tensor, bias: Optional[Tensor]):
+    """Gate backward with the conv outputs recomputed from the conv input x (no stored y)."""
+    _gpu(dg, x, w, bias)
+    B, C2, H, W = x.shape
+    ks = w.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    db = torch.empty(C2, dtype=torch.float32, device=x.device) if bias is not None else None
+    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
+    L.check(L.lib().mi_dwconv_gate_bwd_recompute(_p(dg), _p(x), _p(w), _p(bias), _p(dx), _p(dw), _p(db), B, C2, H, W, ks, 0,
+                                                 _dt(x), _p(ws), _stream()), "dwconv_gate_bwd_recompute")
+    return dx, dw, db
+
+
 def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
             transposed: bool = False, x2: Optional[Tensor] = None) -> Tensor:
     """y = W x (+bias)(+residual).  x [B,K,H,W]; w [M,K(,1,1)] or, transposed, [K,M(,1,1)] used as W^T.

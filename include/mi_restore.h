@@ -82,6 +82,14 @@ int mi_dwconv_bwd(const void* dy, const void* x, const float* w, void* dx, float
 int mi_dwconv_gate_bwd(const void* dg, const void* y, const void* x, const float* w, void* dx, float* dw,
                        float* db, int B, int C2, int H, int W, int ks, int accumulate, int dtype,
                        void* ws, void* stream);
+/* GDFN gate backward WITHOUT stored conv outputs: y1, y2 are recomputed from the conv input x inside the kernel (the
+ * input rows are needed for the weight gradient anyway), so the forward need not write y at all (mi_dwconv_gate_fwd with
+ * y = NULL) - a third less HBM traffic over the depthwise stage and 2h fewer saved planes.  Available for the shapes
+ * mi_dwconv_gate_recompute_ok() reports (3x3, rows of 16..256 pixels, power of two); same workspace as mi_dwconv_gate_bwd. */
+int mi_dwconv_gate_recompute_ok(int H, int W, int ks);
+int mi_dwconv_gate_bwd_recompute(const void* dg, const void* x, const float* w, const float* bias, void* dx, float* dw,
+                                 float* db, int B, int C2, int H, int W, int ks, int accumulate, int dtype, void* ws,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------
  * Pointwise (1x1 conv) GEMM on N-contiguous planes (Restormer.py:82,86,105,107):

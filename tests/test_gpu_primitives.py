@@ -118,6 +118,33 @@ def test_dwconv_gate_fwd_bwd(dtype, shape):
     assert rel(db, ys.grad.sum(dim=(0, 2, 3))) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("shape", [(2, 10, 16, 64), (1, 254, 16, 16), (2, 6, 40, 256), (1, 4, 9, 32), (3, 2, 5, 128)])
+def test_dwconv_gate_bwd_recompute(dtype, bias, shape):
+    """Gate backward with y recomputed from the conv input (no stored y): dx, dW, db against autograd through
+    conv -> chunk -> gelu(y1) * y2 in fp64; band edges (H not a multiple of the band), several bands, all row widths."""
+    o = ops()
+    B, C2, H, W = shape
+    h = C2 // 2
+    assert o.dwconv_gate_recompute_ok(H, W, 3)
+    x = rnd(shape, 41).to(dtype)
+    w = rnd((C2, 1, 3, 3), 42) / 3
+    bv = 0.1 * rnd((C2,), 43) if bias else None
+    dg = rnd((B, h, H, W), 44).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = bv.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1, groups=C2)
+    (F.gelu(yr[:, :h]) * yr[:, h:]).backward(dg.double())
+    dx, dw, db = o.dwconv_gate_bwd_recompute(dg.to(DEV), x.to(DEV), w.to(DEV), bv.to(DEV) if bias else None)
+    assert rel(dx, xr.grad) < TOL[dtype]
+    assert rel(dw, wr.grad) < TOL[dtype]
+    if bias:
+        assert rel(db, br.grad) < TOL[dtype]
+    assert not o.dwconv_gate_recompute_ok(7, 9, 3) and not o.dwconv_gate_recompute_ok(16, 16, 7)
+
+
 # --------------------------------------------------------------------------- pointwise GEMM
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("transposed", [False, True])

@@ -63,7 +63,7 @@ def bench_ln():
 def bench_dw():
     from image_restoration_amd import ops
     for (C, H, W) in [(144, 256, 256), (254, 256, 256), (288, 256, 256), (510, 128, 128), (1020, 64, 64)]:
-        B = 8
+        B = int(os.environ.get("BK_BATCH", "8"))
         x = torch.randn(B, C, H, W, device="cuda").bfloat16()
         w = torch.randn(C, 1, 3, 3, device="cuda")
         us = timeit(lambda: ops.dwconv_fwd(x, w, None))
@@ -76,6 +76,10 @@ def bench_dw():
             dg = x[:, : C // 2].contiguous()
             us = timeit(lambda: ops.dwconv_gate_bwd(dg, x, x, w, False))
             print(f"dw_gate_bwd C={C} {H}x{W}: {us:8.1f} us {3.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+            us = timeit(lambda: ops.dwconv_gate_bwd_recompute(dg, x, w, None))
+            print(f"dw_gate_bwd_recompute C={C} {H}x{W}: {us:8.1f} us {2.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
+            us = timeit(lambda: ops.dwconv_gate_fwd(x, w, None, want_y=False))
+            print(f"dw_gate_fwd(no y) C={C} {H}x{W}: {us:8.1f} us {1.5 * x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
 
 
 def bench_gram():
