@@ -115,10 +115,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_ONE_DEVICE=1: rehearsal of the N>1 code path on a single-GPU box - every rank uses cuda:0 and the collectives
+    # go through gloo (RCCL refuses two ranks on one device).  Not a measurement mode.
+    one_dev = os.environ.get("BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
