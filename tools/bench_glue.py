@@ -13,7 +13,8 @@ net = m.Restormer(**R.RESTORMER_BASE).to(dev)
 for name in ("encoder_level1", "encoder_level2", "encoder_level3", "latent", "decoder_level3", "decoder_level2",
              "decoder_level1", "refinement"):
     setattr(net, name, torch.nn.Identity())
-x = torch.rand(8, 3, 256, 256, device=dev).bfloat16()
+import os
+x = torch.rand(int(os.environ.get("BK_BATCH", "8")), 3, 256, 256, device=dev).bfloat16()
 def step():
     for p in net.parameters():
         p.grad = None
