@@ -434,6 +434,11 @@ static GramSPlan gram_splan(const mi_gram_desc* d) {
   g.ss_bytes = align_up((size_t)g.splits * g.Z * (d->ma + d->mb) * sizeof(float), 256);
   return g;
 }
+// One split, one output slice per z, plain overwrite into a dense [Z][ma][mb] output: the kernel's "partial" IS the result,
+// so it writes straight to the output and the reduce launch disappears (dM = dy v^T at C = 384: a 19 MB copy at 330 GB/s).
+static bool gram_direct(const mi_gram_desc* d, int splits) {
+  return splits == 1 && !d->sum_batch && !d->accumulate && d->out_ld == d->mb && d->out_zs == (int64_t)d->ma * d->mb;
+}
 static bool gram_stream_ok(const mi_gram_desc* d) {
   if (d->dtype != MI_BF16 || getenv("MI_GRAM_LDS")) return false;
   bool ok = (d->n % 8 == 0) && aligned16(d->a) && aligned16(d->b);
@@ -471,7 +476,8 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
   k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
   k.n = d->n; k.groups = d->groups; k.Z = g.Z;
-  k.part = (float*)ws;
+  const bool direct = gram_direct(d, g.splits);
+  k.part = direct ? d->out : (float*)ws;
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
   k.chunks_per_split = 0; k.nchunks = 0; k.tiles_b = g.tiles_b; k.vec_ok = 1;
   dim3 grid(g.splits, g.tiles_a * g.tiles_b, g.Z), block(256);
@@ -490,12 +496,14 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
 #undef GS_CASE
   }
   MI_LAUNCH_CHECK();
-  ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
-  const int zo = d->sum_batch ? d->groups : g.Z;
-  const int64_t per = (int64_t)d->ma * d->mb;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
-                     d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
-  MI_LAUNCH_CHECK();
+  if (!direct) {
+    ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
+    const int zo = d->sum_batch ? d->groups : g.Z;
+    const int64_t per = (int64_t)d->ma * d->mb;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
+                       d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    MI_LAUNCH_CHECK();
+  }
   if (ss) {
     const int64_t cols = (int64_t)g.Z * (d->ma + d->mb);
     MI_TRY(launch_reduce_rows(k.ss_part, d->sumsq, g.splits, cols, cols, 0, 1.0f, st));
@@ -522,7 +530,8 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
   k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
   k.n = d->n; k.groups = d->groups; k.Z = g.Z;
-  k.part = (float*)ws;
+  const bool direct = gram_direct(d, g.splits);
+  k.part = direct ? d->out : (float*)ws;
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
   k.chunks_per_split = g.cps; k.nchunks = g.nchunks; k.tiles_b = g.tiles_b;
   const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
@@ -546,12 +555,14 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
 #undef GRAM_CASE
   }
   MI_LAUNCH_CHECK();
-  ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
-  const int zo = d->sum_batch ? d->groups : g.Z;
-  const int64_t per = (int64_t)d->ma * d->mb;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
-                     d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
-  MI_LAUNCH_CHECK();
+  if (!direct) {
+    ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
+    const int zo = d->sum_batch ? d->groups : g.Z;
+    const int64_t per = (int64_t)d->ma * d->mb;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
+                       d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    MI_LAUNCH_CHECK();
+  }
   if (ss) {
     const int64_t cols = (int64_t)g.Z * (d->ma + d->mb);
     MI_TRY(launch_reduce_rows(k.ss_part, d->sumsq, g.splits, cols, cols, 0, 1.0f, st));
