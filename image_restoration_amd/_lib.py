@@ -99,7 +99,7 @@ SIGNATURES = {
                                                C.c_int, C.c_int, vp, vp]),
     "mi_pw_gemm_workspace": (C.c_size_t, [C.POINTER(PwDesc)]),
     "mi_pw_gemm": (C.c_int, [C.POINTER(PwDesc), vp, vp]),
-    "mi_pw_cache_enable": (C.c_int, [vp, C.c_size_t]),
+    "mi_pw_cache_enable": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "mi_pw_cache_refresh": (C.c_int, [vp]),
     "mi_pw_cache_invalidate": (C.c_int, []),
     "mi_gram_workspace": (C.c_size_t, [C.POINTER(GramDesc)]),
@@ -121,6 +121,9 @@ SIGNATURES = {
                               vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, fp, vp]),
+    "mi_glue3x3_ok": (C.c_int, [C.c_int, C.c_int]),
+    "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_gap_fwd": (C.c_int, [vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_gap_bwd": (C.c_int, [fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),

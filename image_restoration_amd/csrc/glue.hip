@@ -1,0 +1,211 @@
+// U-Net glue, thin 3x3 convolutions: OverlapPatchEmbed 3 -> 48 (Restormer.py:156-165) and the output
+// conv 96 -> 3 (+ input residual, Restormer.py:243,281).  At 256^2 these move 50-100 planes for 3, i.e. they are pure
+// HBM streams (ideal 45-80 us at bs 32), and MIOpen's implicit-GEMM kernels take 0.9-1.0 ms each.  They are built here from
+// the 1x1 GEMM / Gram kernels plus two streaming layout kernels:
+//   im2col3x3 : x[B,C,H,W] (C tiny) -> col[B,9C,H,W],  col[c*9+ky*3+kx][y][x] = x[c][y+ky-1][x+kx-1]   (flip: shifts negated)
+//   col2im3x3 : z[B,9M,H,W]         -> y[B,M,H,W],     y[m][y][x] = sum_taps z[m*9+ky*3+kx][y+ky-1][x+kx-1] (+bias +residual)
+//               (flip: shifts negated - the scatter of a transposed convolution)
+// so that   conv(x; W) = W[Cout, 9Cin] . im2col(x)                 when Cin is tiny  (weight gradient: Gram(dy, im2col(x)))
+//           conv(x; W) = col2im(Wz[9Cout, Cin] . x)                when Cout is tiny (d z = im2col_flipped(dy))
+// Same wave-streaming scheme as dwstream.hip: a wave owns a band of rows of one plane, a lane 4 pixels, neighbours by DPP.
+#include "common.h"
+
+namespace mi {
+namespace {
+
+template <typename T> struct GRaw;
+template <> struct GRaw<bf16> {
+  using V = u32x2;
+  static __device__ __forceinline__ V zero() { V z = {0u, 0u}; return z; }
+  static __device__ __forceinline__ void expand(const V& t, float* o) {
+    o[0] = bf16_bits_to_f32(t[0] & 0xffffu); o[1] = bf16_bits_to_f32(t[0] >> 16);
+    o[2] = bf16_bits_to_f32(t[1] & 0xffffu); o[3] = bf16_bits_to_f32(t[1] >> 16);
+  }
+};
+template <> struct GRaw<float> {
+  using V = f32x4;
+  static __device__ __forceinline__ V zero() { V z = {0.f, 0.f, 0.f, 0.f}; return z; }
+  static __device__ __forceinline__ void expand(const V& t, float* o) { o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; }
+};
+template <int CTRL> __device__ __forceinline__ float g_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// r[0] = pixel left of the lane's 4, r[1..4] = own, r[5] = right; zero outside the row
+__device__ __forceinline__ void g_window(const float* v, bool first, bool last, float* r) {
+  const float l = g_dpp<0x138>(v[3]);  // wave_shr:1
+  const float g = g_dpp<0x130>(v[0]);  // wave_shl:1
+  r[0] = first ? 0.f : l;
+  r[1] = v[0]; r[2] = v[1]; r[3] = v[2]; r[4] = v[3];
+  r[5] = last ? 0.f : g;
+}
+
+// which band of which plane this lane group works on (LPR lanes per row, 64/LPR bands side by side in a wave)
+template <int LPR> struct GUnit {
+  int lx, plane, y0;
+  bool active;
+  __device__ __forceinline__ GUnit(int planes, int nb, int band_rows) {
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    lx = lane % LPR;
+    const int64_t u = ((int64_t)blockIdx.x * 4 + wave) * G + lane / LPR;
+    plane = (int)(u / nb);
+    active = plane < planes;
+    y0 = (int)(u - (int64_t)plane * nb) * band_rows;
+  }
+};
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ out, int planes, int H, int W,
+                                                        int nb, int band_rows, int flip) {
+  using R = GRaw<T>;
+  using RV = typename R::V;
+  const GUnit<LPR> u(planes, nb, band_rows);
+  const int64_t HW = (int64_t)H * W;
+  const int px = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const T* xp = x + (int64_t)(u.active ? u.plane : 0) * HW + px;
+  T* op = out + (int64_t)(u.active ? u.plane : 0) * 9 * HW + px;
+  const int yend = min(u.y0 + band_rows, H);
+  auto ld = [&](int y) -> RV {
+    return (u.active && y >= 0 && y <= yend && y < H) ? *reinterpret_cast<const RV*>(xp + (int64_t)y * W) : R::zero();
+  };
+  float w0[6], w1[6], w2[6], v[4];
+  R::expand(ld(u.y0 - 1), v); g_window(v, first, last, w0);
+  R::expand(ld(u.y0), v); g_window(v, first, last, w1);
+  RV nxt = ld(u.y0 + 1);
+  for (int yy = 0; yy < band_rows; ++yy) {
+    const int y = u.y0 + yy;
+    R::expand(nxt, v);
+    nxt = ld(y + 2);
+    g_window(v, first, last, w2);
+    if (u.active && y < yend) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int src = flip ? 8 - tap : tap;
+        const int ky = src / 3, kx = src - 3 * ky;
+        const float* r = ky == 0 ? w0 : (ky == 1 ? w1 : w2);
+        float o[4] = {r[kx], r[kx + 1], r[kx + 2], r[kx + 3]};
+        Vec<T, 4>::st(op + (int64_t)tap * HW + (int64_t)y * W, o);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { w0[i] = w1[i]; w1[i] = w2[i]; }
+  }
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ z, const float* __restrict__ bias,
+                                                        const T* __restrict__ residual, T* __restrict__ yout, int planes,
+                                                        int M, int H, int W, int nb, int band_rows, int flip) {
+  using R = GRaw<T>;
+  using RV = typename R::V;
+  const GUnit<LPR> u(planes, nb, band_rows);
+  const int64_t HW = (int64_t)H * W;
+  const int px = 4 * u.lx;
+  const bool first = u.lx == 0, last = u.lx == LPR - 1;
+  const int plane = u.active ? u.plane : 0;
+  const T* zp = z + (int64_t)plane * 9 * HW + px;
+  const T* rp = residual ? residual + (int64_t)plane * HW + px : nullptr;
+  T* yp = yout + (int64_t)plane * HW + px;
+  const float bv = bias ? bias[plane % M] : 0.f;
+  const int yend = min(u.y0 + band_rows, H);
+  auto ld = [&](const T* base, int y) -> RV {
+    return (u.active && y >= 0 && y < yend + 1 && y < H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * W) : R::zero();
+  };
+  for (int yy = 0; yy < band_rows; ++yy) {
+    const int y = u.y0 + yy;
+    RV raw[9], rres = R::zero();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) raw[tap] = ld(zp + (int64_t)(flip ? 8 - tap : tap) * HW, y + tap / 3 - 1);   // flip: plane of the opposite tap
+    if (rp && u.active && y < yend) rres = *reinterpret_cast<const RV*>(rp + (int64_t)y * W);
+    float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kx = tap % 3;
+      float v[4], r[6];
+      R::expand(raw[tap], v);
+      if (kx == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      } else {
+        g_window(v, first, last, r);       // uniform control flow: every lane takes part in the DPP exchange
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += r[j + kx];
+      }
+    }
+    float rr[4];
+    R::expand(rres, rr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += rr[j];
+    if (u.active && y < yend) Vec<T, 4>::st(yp + (int64_t)y * W, acc);
+  }
+}
+
+struct GPlan { int band, nb; unsigned blocks; };
+static GPlan g_plan(int H, int W, int64_t planes) {
+  const int lpr = W / 4, G = 64 / lpr;
+  GPlan p;
+  p.band = 8;
+  for (int band : {32, 16})
+    if (planes * cdiv(H, band) / G >= 4096) { p.band = band; break; }
+  p.nb = cdiv(H, p.band);
+  p.blocks = (unsigned)((planes * p.nb + 4 * G - 1) / (4 * G));
+  return p;
+}
+static bool g_ok(int H, int W) { return H >= 1 && (W == 16 || W == 32 || W == 64 || W == 128 || W == 256); }
+
+#define G_LPR_SWITCH(W_, ...)                                      \
+  switch ((W_) / 4) {                                              \
+    case 64: { constexpr int LPR = 64; __VA_ARGS__; } break;       \
+    case 32: { constexpr int LPR = 32; __VA_ARGS__; } break;       \
+    case 16: { constexpr int LPR = 16; __VA_ARGS__; } break;       \
+    case 8: { constexpr int LPR = 8; __VA_ARGS__; } break;         \
+    default: { constexpr int LPR = 4; __VA_ARGS__; } break;        \
+  }
+
+}  // namespace
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_glue3x3_ok(int H, int W) { return g_ok(H, W) ? 1 : 0; }
+
+extern "C" int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip, int dtype, void* stream) {
+  MI_CHECK_ARG(x && out && B > 0 && C > 0, "im2col3x3: bad arguments");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "im2col3x3: bad dtype %d", dtype);
+  MI_CHECK_ARG(g_ok(H, W) && aligned16(x) && aligned16(out), "im2col3x3: rows must be 16..256 pixels (power of two), planes 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t planes = (int64_t)B * C;
+  const GPlan p = g_plan(H, W, planes);
+  ProfScope ps(st, K_IM2COL, 10.0 * planes * H * W * dtype_size(dtype), 0.0);
+  if (dtype == MI_F32) {
+    G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<float, LPR>), dim3(p.blocks), dim3(256), 0, st, (const float*)x, (float*)out,
+                                       (int)planes, H, W, p.nb, p.band, flip));
+  } else {
+    G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<bf16, LPR>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out,
+                                       (int)planes, H, W, p.nb, p.band, flip));
+  }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_col2im3x3(const void* z, const float* bias, const void* residual, void* y, int B, int M, int H, int W,
+                            int flip, int dtype, void* stream) {
+  MI_CHECK_ARG(z && y && B > 0 && M > 0, "col2im3x3: bad arguments");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "col2im3x3: bad dtype %d", dtype);
+  MI_CHECK_ARG(g_ok(H, W) && aligned16(z) && aligned16(y) && aligned16(residual),
+               "col2im3x3: rows must be 16..256 pixels (power of two), planes 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t planes = (int64_t)B * M;
+  const GPlan p = g_plan(H, W, planes);
+  ProfScope ps(st, K_COL2IM, (10.0 + (residual ? 1.0 : 0.0)) * planes * H * W * dtype_size(dtype), 9.0 * planes * H * W);
+  if (dtype == MI_F32) {
+    G_LPR_SWITCH(W, hipLaunchKernelGGL((col2im3x3_kernel<float, LPR>), dim3(p.blocks), dim3(256), 0, st, (const float*)z, bias,
+                                       (const float*)residual, (float*)y, (int)planes, M, H, W, p.nb, p.band, flip));
+  } else {
+    G_LPR_SWITCH(W, hipLaunchKernelGGL((col2im3x3_kernel<bf16, LPR>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)z, bias,
+                                       (const bf16*)residual, (bf16*)y, (int)planes, M, H, W, p.nb, p.band, flip));
+  }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}

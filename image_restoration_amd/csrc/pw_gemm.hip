@@ -572,6 +572,8 @@ struct PwCache {
   std::vector<PackJob> jobs;
   bool dirty = false;   // host table newer than the device copy
   bool valid = false;   // packed images match the weights (set by refresh, cleared by invalidate / new entries)
+  const char* lo = nullptr;   // only weights inside [lo, hi) are cached: the caller's parameter storage.  A temporary
+  const char* hi = nullptr;   // (a permuted copy, say) may reuse an address with other values and must never hit.
 };
 static PwCache g_pwc;
 constexpr size_t PWC_TABLE_ENTRIES = 4096;
@@ -586,6 +588,7 @@ static bool same_job(const PackJob& a, const PackJob& b) {
 static const unsigned char* pw_cache_lookup(const PackJob& j, size_t image_bytes, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_pwc.mu);
   if (!g_pwc.base || j.w_bs != 0) return nullptr;                 // per-image weights are never cached
+  if ((const char*)j.w < g_pwc.lo || (const char*)j.w >= g_pwc.hi) return nullptr;   // not in the registered parameter storage
   for (const PackJob& e : g_pwc.jobs)
     if (same_job(e, j)) return g_pwc.valid && !g_pwc.dirty ? e.ws : nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -701,10 +704,11 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   return pw_launch<bf16>(d, k, pl, ws, st);
 }
 
-extern "C" int mi_pw_cache_enable(void* buf, size_t bytes) {
+extern "C" int mi_pw_cache_enable(void* buf, size_t bytes, const void* params_lo, const void* params_hi) {
   std::lock_guard<std::mutex> lk(g_pwc.mu);
   g_pwc.jobs.clear();
   g_pwc.valid = false; g_pwc.dirty = false; g_pwc.used = 0; g_pwc.base = nullptr; g_pwc.bytes = 0;
+  g_pwc.lo = (const char*)params_lo; g_pwc.hi = (const char*)params_hi;
   if (!buf) return MI_OK;  // disable
   g_pwc.table_bytes = align_up(PWC_TABLE_ENTRIES * sizeof(PackJob), 256);
   MI_CHECK_ARG(aligned16(buf) && bytes > g_pwc.table_bytes + 4096, "pw_cache_enable: buffer too small or misaligned");

@@ -326,6 +326,30 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
 
 
 # ----------------------------------------------------------------------------- router GAP
+def glue3x3_ok(H: int, W: int) -> bool:
+    return bool(L.lib().mi_glue3x3_ok(H, W))
+
+
+def im2col3x3(x: Tensor, flip: bool = False) -> Tensor:
+    """x[B,C,H,W] -> [B,9C,H,W] with col[c*9+ky*3+kx][y][x] = x[c][y+ky-1][x+kx-1] (shifts negated when flip)."""
+    _gpu(x)
+    B, Cn, H, W = x.shape
+    out = torch.empty((B, 9 * Cn, H, W), dtype=x.dtype, device=x.device)
+    L.check(L.lib().mi_im2col3x3(_p(x), _p(out), B, Cn, H, W, 1 if flip else 0, _dt(x), _stream()), "im2col3x3")
+    return out
+
+
+def col2im3x3(z: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, flip: bool = False) -> Tensor:
+    """z[B,9M,H,W] -> y[B,M,H,W], y[m] = sum over taps of the tap plane shifted back (+ bias[m]) (+ residual);
+    flip negates the shifts (transposed convolution)."""
+    _gpu(z, bias, residual)
+    B, M9, H, W = z.shape
+    M = M9 // 9
+    y = torch.empty((B, M, H, W), dtype=z.dtype, device=z.device)
+    L.check(L.lib().mi_col2im3x3(_p(z), _p(_f32(bias, "bias")), _p(residual), _p(y), B, M, H, W, 1 if flip else 0, _dt(z), _stream()), "col2im3x3")
+    return y
+
+
 def gap_fwd(x: Tensor) -> Tensor:
     _gpu(x)
     B, Cc, H, W = x.shape
@@ -365,16 +389,19 @@ def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
 _pw_cache_buf: Optional[Tensor] = None
 
 
-def pw_cache_enable(nbytes: int, device) -> None:
-    """Lend the library a device buffer for packed 1x1 weights (include/mi_restore.h: mi_pw_cache_*).  The caller
-    promises to call pw_cache_refresh() after every in-place weight update (or pw_cache_invalidate())."""
+def pw_cache_enable(nbytes: int, device, params: Optional[Tensor] = None) -> None:
+    """Lend the library a device buffer for packed 1x1 weights (include/mi_restore.h: mi_pw_cache_*).  `params` is the
+    storage that holds the weights (e.g. the trainer's flat parameter buffer): only matrices inside it are cached.  The
+    caller promises to call pw_cache_refresh() after every in-place weight update (or pw_cache_invalidate())."""
     global _pw_cache_buf
-    if nbytes <= 0:
-        L.check(L.lib().mi_pw_cache_enable(None, 0), "pw_cache_enable")
+    if nbytes <= 0 or params is None:
+        L.check(L.lib().mi_pw_cache_enable(None, 0, None, None), "pw_cache_enable")
         _pw_cache_buf = None
         return
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    L.check(L.lib().mi_pw_cache_enable(buf.data_ptr(), nbytes), "pw_cache_enable")
+    lo = params.data_ptr()
+    L.check(L.lib().mi_pw_cache_enable(buf.data_ptr(), nbytes, lo, lo + params.numel() * params.element_size()),
+            "pw_cache_enable")
     _pw_cache_buf = buf  # keeps the memory alive for as long as the cache points at it
 
 

@@ -374,7 +374,70 @@ class TransformerBlock(nn.Module):
         return _BlockFn.apply(x, self.attn.num_heads, *params)
 
 
-def _conv2d(x: Tensor, conv: nn.Conv2d) -> Tensor:
+class _ThinConv3x3Fn(torch.autograd.Function):
+    """Dense 3x3 convolution (stride 1, pad 1) where one side has <= 4 channels, built from the native 1x1 GEMM / Gram plus
+    the im2col3x3 / col2im3x3 layout kernels (csrc/glue.hip).  These are Restormer's OverlapPatchEmbed (3 -> dim,
+    Restormer.py:156-165) and output conv (2*dim -> 3 plus the input residual, Restormer.py:243,281): pure HBM streams
+    that MIOpen's implicit-GEMM kernels run 10-20x off their roofline.
+      Cin tiny : y = W[Cout,9Cin] . im2col(x);            dW = Gram(dy, im2col(x));  dx = col2im(W^T . dy)
+      Cout tiny: y = col2im(Wz[9Cout,Cin] . x) (+b)(+res); dz = im2col_flipped(dy);   dx = Wz^T . dz;  dWz = Gram(dz, x)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        cout, cin = weight.shape[0], weight.shape[1]
+        ctx.small_in = cin <= cout
+        if ctx.small_in:
+            xcol = ops.im2col3x3(x)
+            y = ops.conv1x1(xcol, weight.reshape(cout, cin * 9), bias, residual)
+            saved = xcol
+        else:
+            wz = weight.permute(0, 2, 3, 1).reshape(cout * 9, cin).contiguous()      # [(co,ky,kx), ci]; a few KB
+            y = ops.col2im3x3(ops.conv1x1(x, wz), bias, residual)
+            saved = x
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(saved, weight)
+            ctx.has_bias = bias is not None
+            ctx.mg = _main_grads((weight, bias))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = weight.shape[0], weight.shape[1]
+        dx = None
+        if ctx.small_in:
+            dw = ops.gram(dy, saved, 1, True)[0].reshape(weight.shape)                # [Cout, 9Cin]
+            if ctx.needs_input_grad[0]:
+                dx = ops.col2im3x3(ops.conv1x1(dy, weight.reshape(cout, cin * 9), None, None, True), flip=True)
+        else:
+            dz = ops.im2col3x3(dy, flip=True)                                          # [(co,ky,kx)] planes
+            dwz = ops.gram(dz, saved, 1, True)[0]                                      # [9Cout, Cin]
+            dw = dwz.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[0]:
+                wz = weight.permute(0, 2, 3, 1).reshape(cout * 9, cin).contiguous()
+                dx = ops.conv1x1(dz, wz, None, None, True)
+        db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        dres = dy if ctx.needs_input_grad[3] else None
+        if ctx.mg is not None:
+            ctx.mg[0].add_(dw)
+            if db is not None:
+                ctx.mg[1].add_(db)
+            return dx, None, None, dres
+        return dx, dw.contiguous(), db, dres
+
+
+def _conv2d(x: Tensor, conv: nn.Conv2d, residual: Optional[Tensor] = None) -> Tensor:
+    """U-Net glue convolution (dense 3x3).  Thin ones (<= 4 channels on one side) are native
+    (_ThinConv3x3Fn); the C -> C/2 and C -> 2C convs of Down/Upsample are still a PyTorch-ROCm (MIOpen) op."""
+    if (min(conv.weight.shape[0], conv.weight.shape[1]) <= 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and x.is_cuda and ops.glue3x3_ok(x.shape[2], x.shape[3]) and x.is_contiguous()):
+        return _ThinConv3x3Fn.apply(x, conv.weight, conv.bias, residual)
+    y = _conv2d_torch(x, conv)
+    return y if residual is None else y + residual
+
+
+def _conv2d_torch(x: Tensor, conv: nn.Conv2d) -> Tensor:
     """U-Net glue convolution (dense 3x3): SURVEY 8(f) row f1 ("next"), still a PyTorch-ROCm op this round.
     Parameters stay fp32; they are cast to the activation dtype for the call."""
     w = conv.weight if conv.weight.dtype == x.dtype else conv.weight.to(x.dtype)
@@ -475,4 +538,4 @@ class Restormer(nn.Module):
             out_dec_level1 = out_dec_level1 + _Conv1x1Fn.apply(inp_enc_level1, None, self.skip_conv.weight,
                                                                self.skip_conv.bias)
             return _conv2d(out_dec_level1, self.output)
-        return _conv2d(out_dec_level1, self.output) + inp_img
+        return _conv2d(out_dec_level1, self.output, inp_img)

@@ -82,7 +82,7 @@ class FlatTrainer:
         # cache per parameter covers both orientations of every matrix in either activation dtype, plus tile padding.
         self._pack_cache = bool(pack_cache) and dev.type == "cuda"
         if self._pack_cache:
-            ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev)
+            ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat_p)
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self) -> None:

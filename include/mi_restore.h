@@ -116,7 +116,10 @@ int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
 /* Opt-in packed-weight cache.  By default every mi_pw_gemm (and every module entry point built on it) packs its weight
  * matrix into its own workspace, once per call, and the library keeps no state.  A caller that controls when the
  * weights change (a trainer: only at the optimizer step; an inference server: never) may lend a device buffer:
- *   mi_pw_cache_enable(buf, bytes)  buf stays owned by the caller and must outlive the cache; NULL disables it.
+ *   mi_pw_cache_enable(buf, bytes, lo, hi)  buf stays owned by the caller and must outlive the cache; NULL disables it.
+ *                                   Only weights whose address lies in [lo, hi) - the caller's parameter storage - are
+ *                                   cached: a temporary weight matrix (a permuted copy, ...) may reuse an address with
+ *                                   different values and always packs per call.
  *   mi_pw_cache_refresh(stream)     re-packs EVERY weight seen so far in one launch; from then on calls with those
  *                                   weights skip their pack launch.  Call it after each optimizer step (the weights
  *                                   registered since the last refresh are picked up; the first refresh after new
@@ -125,7 +128,7 @@ int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
  *                                   per call again until the next refresh.
  * Per-image weights (w_bs != 0) are never cached.  The cache is process-global and mutex-protected; this is the only
  * mutable state in the library besides the thread-local error string and the profiler.                              */
-int mi_pw_cache_enable(void* buf, size_t bytes);
+int mi_pw_cache_enable(void* buf, size_t bytes, const void* params_lo, const void* params_hi);
 int mi_pw_cache_refresh(void* stream);
 int mi_pw_cache_invalidate(void);
 
@@ -228,6 +231,21 @@ int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, 
 int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale,
                   const float* dev_scalars, void* stream);
+
+/* ------------------------------------------------------------------------
+ * U-Net glue, thin dense 3x3 convolutions (Restormer.py:156-165 OverlapPatchEmbed 3->48; :243,281 output conv 2*dim->3
+ * + input residual).  Layout kernels that turn them into the 1x1 GEMM / Gram above:
+ *   im2col3x3: x[B,C,H,W] -> col[B,9C,H,W], col[c*9+ky*3+kx][y][x] = x[c][y+ky-1][x+kx-1] (zero padded);
+ *              flip != 0 negates the shifts (the im2col of the transposed convolution).
+ *   col2im3x3: z[B,9M,H,W] -> y[B,M,H,W],  y[m][y][x] = sum_taps z[m*9+ky*3+kx][y+ky-1][x+kx-1] (+ bias[m]) (+ residual);
+ *              flip != 0 negates the shifts (scatter of the transposed convolution: input gradient of the im2col form).
+ * conv(x;W) = W[Cout,9Cin] . im2col(x) when Cin is tiny; = col2im(Wz[9Cout,Cin] . x) when Cout is tiny.
+ * Rows of 16..256 pixels, power of two (mi_glue3x3_ok).
+ * ------------------------------------------------------------------------ */
+int mi_glue3x3_ok(int H, int W);
+int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip, int dtype, void* stream);
+int mi_col2im3x3(const void* z, const float* bias, const void* residual, void* y, int B, int M, int H, int W, int flip,
+                 int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * Router global average pool (moce_ir.py:703-707, RoutingFunction.gate[0]): out[b,c] = mean_n x[b,c,n] (fp32);

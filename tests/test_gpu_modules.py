@@ -185,8 +185,14 @@ def test_packed_weight_cache_is_transparent():
 
     ref1, ref2 = go(fresh(1.0)), go(fresh(2.0))   # powers of two: the in-place updates below are exact
     try:
-        ops.pw_cache_enable(32 << 20, torch.device(DEV))
         blk = fresh(1.0)
+        # the cache only takes weights inside the registered parameter storage: move the block's parameters into one
+        flat = torch.cat([p.detach().reshape(-1) for p in blk.parameters()]).contiguous()
+        off = 0
+        for p in blk.parameters():
+            p.data = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        ops.pw_cache_enable(32 << 20, torch.device(DEV), flat)
         go(blk)                      # registers the block's weights (still packs per call)
         ops.pw_cache_refresh()
         for a, b in zip(go(blk), ref1):
@@ -204,4 +210,36 @@ def test_packed_weight_cache_is_transparent():
         for a, b in zip(go(blk), ref1):
             assert torch.equal(a, b)
     finally:
-        ops.pw_cache_enable(0, torch.device(DEV))
+        ops.pw_cache_enable(0, torch.device(DEV), None)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("cin,cout,hw,bias", [(3, 48, (40, 64), False), (96, 3, (24, 128), False), (16, 3, (9, 32), True),
+                                              (3, 16, (33, 256), True)])
+def test_thin_glue_conv3x3_native(dtype, tol, cin, cout, hw, bias):
+    """OverlapPatchEmbed (3 -> dim) and the output conv (2*dim -> 3, + input residual) through the native
+    im2col / col2im + 1x1 GEMM / Gram path (Restormer.py:156-165,243,281) against F.conv2d in fp64."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from image_restoration_amd import restormer as RM
+    torch.manual_seed(5)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=bias)
+    H, W = hw
+    x = seeded_input((2, cin, H, W), 950)
+    res = seeded_input((2, cout, H, W), 951)
+    cot = seeded_input((2, cout, H, W), 952)
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().double().requires_grad_(True)
+    br = conv.bias.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, 1, 1) + res.double()
+    yr.backward(cot.double())
+    conv = conv.to(DEV)
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    assert isinstance(RM._conv2d(xg, conv, res.to(DEV).to(dtype)).grad_fn, RM._ThinConv3x3Fn._backward_cls)
+    y = RM._conv2d(xg, conv, res.to(DEV).to(dtype))
+    y.backward(cot.to(DEV).to(dtype))
+    assert rel(y, yr) < tol
+    assert rel(xg.grad, xr.grad) < tol
+    assert rel(conv.weight.grad, wr.grad) < tol
+    if bias:
+        assert rel(conv.bias.grad, br.grad) < tol
