@@ -350,6 +350,49 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
 // two 3x3 stencils (72 FMAs per lane and row - the VALU is idle in these kernels) and forms d1, d2 from the result:
 // 3 planes read instead of 5, and the forward writes g only.  Rows: d(r) needs x rows r-1..r+1, dx(y) needs d rows
 // y-1..y+1, so a band [y0, yend) reads x rows y0-2 .. yend+1 and dg rows y0-1 .. yend.
+// The two planes of a pair go through identical arithmetic, so they ride in the two halves of packed-fp32 registers
+// (f32x2 = (plane j, plane j+h); v_pk_fma_f32 does both FMAs in one issue slot): the recomputation doubles the stencil
+// work of this kernel and the VALU, not HBM, is what bounds it.
+__device__ __forceinline__ void window_row2(const f32x2* v, bool first, bool last, f32x2* r) {
+  f32x2 l, g;
+  l[0] = dpp_mov<0x138>(v[3][0]); l[1] = dpp_mov<0x138>(v[3][1]);   // wave_shr:1
+  g[0] = dpp_mov<0x130>(v[0][0]); g[1] = dpp_mov<0x130>(v[0][1]);   // wave_shl:1
+  const f32x2 zero = {0.f, 0.f};
+  r[0] = first ? zero : l;
+  r[1] = v[0]; r[2] = v[1]; r[3] = v[2]; r[4] = v[3];
+  r[5] = last ? zero : g;
+}
+template <bool FLIP>
+__device__ __forceinline__ void stencil2(const f32x2* w, f32x2 b, const f32x2* r0, const f32x2* r1, const f32x2* r2, f32x2* o) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x2 s = b;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[FLIP ? 8 - kx : kx] * r0[j + kx];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[FLIP ? 5 - kx : 3 + kx] * r1[j + kx];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) s += w[FLIP ? 2 - kx : 6 + kx] * r2[j + kx];
+    o[j] = s;
+  }
+}
+__device__ __forceinline__ void wgrad_row2(const f32x2* x, const f32x2* up, const f32x2* mid, const f32x2* dn, f32x2* acc) {
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[kx] += x[j] * dn[j - kx + 2];
+      acc[3 + kx] += x[j] * mid[j - kx + 2];
+      acc[6 + kx] += x[j] * up[j - kx + 2];
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[9] += mid[j + 1];
+}
+__device__ __forceinline__ void copy6x2(f32x2* d, const f32x2* s) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d[i] = s[i];
+}
+
 template <typename T, int LPR, bool UNI, bool WANT_DW>
 __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* __restrict__ part, int planes, int nb,
                                                               int band_rows) {
@@ -364,46 +407,51 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
   const T* dgp = (const T*)a.in + ((int64_t)b * h + j) * HW + x;          // dg [B, h, H, W]
   const T* x1p = (const T*)a.gy + ((int64_t)b * a.Cc + j) * HW + x;       // conv input [B, 2h, H, W] (passed in a.gy)
   const T* x2p = x1p + (int64_t)h * HW;
-  float w1[9], w2[9], b1 = 0.f, b2 = 0.f;                                  // forward taps; the transposed conv reads them reversed
+  f32x2 w[9], bias2 = {0.f, 0.f};                                          // (taps of plane j, taps of plane j+h)
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { w1[i] = a.w[(int64_t)j * 9 + i]; w2[i] = a.w[(int64_t)(j + h) * 9 + i]; }
-  if (a.bias) { b1 = a.bias[j]; b2 = a.bias[j + h]; }
+  for (int i = 0; i < 9; ++i) { w[i][0] = a.w[(int64_t)j * 9 + i]; w[i][1] = a.w[(int64_t)(j + h) * 9 + i]; }
+  if (a.bias) { bias2[0] = a.bias[j]; bias2[1] = a.bias[j + h]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
     return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
   };
-  float hA1[6], hB1[6], hC1[6], hA2[6], hB2[6], hC2[6];                    // x rows rho-1, rho, rho+1 of both planes
-  float p0[6], p1[6], p2[6], q0[6], q1[6], q2[6];                          // d1 / d2 rows y-1, y, y+1
-  float acc1[WANT_DW ? 10 : 1], acc2[WANT_DW ? 10 : 1];
+  f32x2 hA[6], hB[6], hC[6];            // x rows rho-1, rho, rho+1
+  f32x2 p0[6], p1[6], p2[6];            // (d1, d2) rows y-1, y, y+1
+  f32x2 acc[WANT_DW ? 10 : 1];
+  const f32x2 zero2 = {0.f, 0.f};
   if (WANT_DW) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
+    for (int i = 0; i < 10; ++i) acc[i] = zero2;
   }
+  auto pair_row = [&](const RV& r1, const RV& r2, f32x2* out4) {
+    float v1[4], v2[4];
+    R::expand(r1, v1); R::expand(r2, v2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { out4[q][0] = v1[q]; out4[q][1] = v2[q]; }
+  };
   // d row rho from dg row rho and x rows rho-1 (hA), rho (hB), rho+1 (raw, becomes hC); rows outside the image give d = 0
-  auto d_row = [&](int rho, const RV& rdg, const RV& rx1, const RV& rx2, float* pd, float* qd) {
-    float v[4], dg[4], y1[4], y2[4], d1[4], d2[4];
-    R::expand(rx1, v); window_row(v, first, last, hC1);
-    R::expand(rx2, v); window_row(v, first, last, hC2);
-    stencil(w1, b1, hA1, hB1, hC1, y1);
-    stencil(w2, b2, hA2, hB2, hC2, y2);
-    R::expand(rdg, dg);                          // zero for rows outside the image / band halo limits
+  auto d_row = [&](int rho, const RV& rdg, const RV& rx1, const RV& rx2, f32x2* pd) {
+    f32x2 xv[4], y[4], d[4];
+    float dg[4];
+    pair_row(rx1, rx2, xv);
+    window_row2(xv, first, last, hC);
+    stencil2<false>(w, bias2, hA, hB, hC, y);       // (y1, y2) in fp32, exactly what the forward gated
+    R::expand(rdg, dg);                             // zero for rows outside the image / band halo limits
     const bool inside = rho >= 0 && rho < a.H;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float a1 = y1[q], a2 = y2[q];      // fp32, exactly what the forward gated (it does not store y either)
       float cdf, pdf;
-      gelu_parts(a1, cdf, pdf);
-      d1[q] = inside ? dg[q] * a2 * (cdf + a1 * pdf) : 0.f;
-      d2[q] = inside ? dg[q] * a1 * cdf : 0.f;
+      gelu_parts(y[q][0], cdf, pdf);
+      d[q][0] = inside ? dg[q] * y[q][1] * (cdf + y[q][0] * pdf) : 0.f;
+      d[q][1] = inside ? dg[q] * y[q][0] * cdf : 0.f;
     }
-    window_row(d1, first, last, pd);
-    window_row(d2, first, last, qd);
+    window_row2(d, first, last, pd);
   };
-  auto h_shift = [&]() { copy6(hA1, hB1); copy6(hB1, hC1); copy6(hA2, hB2); copy6(hB2, hC2); };
+  auto h_shift = [&]() { copy6x2(hA, hB); copy6x2(hB, hC); };
 
   RV cg[PFG], c1[PFG], c2[PFG];
   {
-    float v[4];
+    f32x2 v[4];
     const RV ra1 = ld(x1p, u.y0 - 2, yend + 1), ra2 = ld(x2p, u.y0 - 2, yend + 1);
     const RV rb1 = ld(x1p, u.y0 - 1, yend + 1), rb2 = ld(x2p, u.y0 - 1, yend + 1);
     const RV rc1 = ld(x1p, u.y0, yend + 1), rc2 = ld(x2p, u.y0, yend + 1);
@@ -415,12 +463,10 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
       c1[i] = ld(x1p, u.y0 + 2 + i, yend + 1);
       c2[i] = ld(x2p, u.y0 + 2 + i, yend + 1);
     }
-    R::expand(ra1, v); window_row(v, first, last, hA1);
-    R::expand(ra2, v); window_row(v, first, last, hA2);
-    R::expand(rb1, v); window_row(v, first, last, hB1);
-    R::expand(rb2, v); window_row(v, first, last, hB2);
-    d_row(u.y0 - 1, g0, rc1, rc2, p0, q0); h_shift();
-    d_row(u.y0, g1, rd1, rd2, p1, q1); h_shift();
+    pair_row(ra1, ra2, v); window_row2(v, first, last, hA);
+    pair_row(rb1, rb2, v); window_row2(v, first, last, hB);
+    d_row(u.y0 - 1, g0, rc1, rc2, p0); h_shift();
+    d_row(u.y0, g1, rd1, rd2, p1); h_shift();
   }
   T* o1p = a.out ? (T*)a.out + ((int64_t)b * a.Cc + j) * HW + x : nullptr;
   T* o2p = o1p ? o1p + (int64_t)h * HW : nullptr;
@@ -430,36 +476,32 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
       const int y = u.y0 + yy + i;
       const bool st = u.active && y < yend;
       // now hA = x row y, hB = x row y+1; the raw slots hold dg row y+1 and x row y+2
-      d_row(y + 1, cg[i], c1[i], c2[i], p2, q2);
+      d_row(y + 1, cg[i], c1[i], c2[i], p2);
       cg[i] = ld(dgp, y + PFG + 1, yend); c1[i] = ld(x1p, y + PFG + 2, yend + 1); c2[i] = ld(x2p, y + PFG + 2, yend + 1);
       if (o1p) {
-        float o[4], wt[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wt[k] = w1[8 - k];
-        stencil(wt, 0.f, p0, p1, p2, o);
-        if (st) store4(o1p + (int64_t)y * a.W, o);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wt[k] = w2[8 - k];
-        stencil(wt, 0.f, q0, q1, q2, o);
-        if (st) store4(o2p + (int64_t)y * a.W, o);
+        f32x2 o[4];
+        stencil2<true>(w, zero2, p0, p1, p2, o);
+        if (st) {
+          float oa[4] = {o[0][0], o[1][0], o[2][0], o[3][0]}, ob[4] = {o[0][1], o[1][1], o[2][1], o[3][1]};
+          store4(o1p + (int64_t)y * a.W, oa);
+          store4(o2p + (int64_t)y * a.W, ob);
+        }
       }
-      if (WANT_DW && y < yend) {
-        wgrad_row(&hA1[1], p0, p1, p2, acc1);    // x row y, own 4 pixels
-        wgrad_row(&hA2[1], q0, q1, q2, acc2);
-      }
+      if (WANT_DW && y < yend) wgrad_row2(&hA[1], p0, p1, p2, acc);    // x row y, own 4 pixels
       h_shift();
-      copy6(p0, p1); copy6(p1, p2); copy6(q0, q1); copy6(q1, q2);
+      copy6x2(p0, p1); copy6x2(p1, p2);
     }
   }
   if (WANT_DW) {
+    float a1[10], a2[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) { acc1[i] = group_sum<LPR>(acc1[i]); acc2[i] = group_sum<LPR>(acc2[i]); }
+    for (int i = 0; i < 10; ++i) { a1[i] = group_sum<LPR>(acc[i][0]); a2[i] = group_sum<LPR>(acc[i][1]); }
     if (u.active && u.lx == 0) {
       float* prow = part + ((int64_t)b * nb + u.band) * ((int64_t)a.Cc * 10);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { prow[(int64_t)j * 9 + i] = acc1[i]; prow[(int64_t)(j + h) * 9 + i] = acc2[i]; }
-      prow[(int64_t)a.Cc * 9 + j] = acc1[9];
-      prow[(int64_t)a.Cc * 9 + j + h] = acc2[9];
+      for (int i = 0; i < 9; ++i) { prow[(int64_t)j * 9 + i] = a1[i]; prow[(int64_t)(j + h) * 9 + i] = a2[i]; }
+      prow[(int64_t)a.Cc * 9 + j] = a1[9];
+      prow[(int64_t)a.Cc * 9 + j + h] = a2[9];
     }
   }
 }

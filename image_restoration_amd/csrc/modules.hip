@@ -274,14 +274,14 @@ static int xmdta_check(const mi_xmdta_shape* s) {
 }
 
 // ------------------------------------------------------------------ GDFN
-// Saved for backward: the conv input h0 (2h planes), the conv output h1 (2h planes) and the gate output g (h planes).
-// MI_GDFN_RECOMPUTE=1 drops h1 (40% of the GDFN's saved bytes) and lets backward recompute it from h0
-// (mi_dwconv_gate_bwd_recompute).  It is NOT the default: beyond the Infinity Cache the forward gains 173 us per launch
-// from not writing y (539 -> 366 us, C=254 at 256^2, bs 32) but the recomputing backward loses 242 us (732 -> 975 us): with
-// two more 3x3 stencils per row it is VALU-bound at 2.7 TB/s (profiles/r01_z_gdfn_recompute_bs32.log).
+// Saved for backward: the conv input h0 (2h planes) and the gate output g (h planes).  The conv OUTPUT h1 (2h planes, 40%
+// of the GDFN's saved bytes) is stored only where the backward kernel cannot recompute it from h0 (5x5 / 7x7, odd row
+// widths; mi_dwconv_gate_recompute_ok) or when MI_GDFN_STORE_Y=1 asks for the old behaviour.  Beyond the Infinity Cache
+// (bs 32, C=254 at 256^2) forward + backward of the depthwise stage take 376 + 685 us this way against 540 + 741 us with a
+// stored y; the recomputing backward needed packed-fp32 math for that (975 us without: VALU-bound).
 struct GdfnSaved { void* h0; void* h1; void* g; size_t bytes; };
 static bool gdfn_recompute(const mi_gdfn_shape* s) {
-  return getenv("MI_GDFN_RECOMPUTE") && mi_dwconv_gate_recompute_ok(s->H, s->W, s->ks) != 0;
+  return !getenv("MI_GDFN_STORE_Y") && mi_dwconv_gate_recompute_ok(s->H, s->W, s->ks) != 0;
 }
 static GdfnSaved gdfn_saved_layout(const mi_gdfn_shape* s, void* base) {
   const size_t N = (size_t)s->H * s->W, B = s->B, h = s->hidden;

@@ -42,7 +42,8 @@ def test_sizing_and_argument_errors_without_gpu(lib):
     assert L.lib().mi_mdta_saved_bytes(C.byref(s)) > 2 * 2 * 144 * 256 * 4
     assert L.lib().mi_mdta_workspace(C.byref(s)) > 0
     g = L.GdfnShape(2, 48, 127, 16, 16, L.MI_BF16, 3)
-    assert L.lib().mi_gdfn_saved_bytes(C.byref(g)) >= 2 * (254 + 254 + 127) * 256 * 2
+    # conv input (2h planes) + gate output (h planes); the conv output is recomputed in backward for 3x3 on 16-pixel rows
+    assert L.lib().mi_gdfn_saved_bytes(C.byref(g)) >= 2 * (254 + 127) * 256 * 2
     bad = L.MdtaShape(2, 50, 4, 16, 16, L.MI_F32, 3)   # 50 channels not divisible by 4 heads
     assert L.lib().mi_mdta_saved_bytes(C.byref(bad)) == 0
     assert b"divisible" in L.lib().mi_last_error()

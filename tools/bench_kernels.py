@@ -94,6 +94,9 @@ def bench_gram():
         us = timeit(lambda: ops.gram(a, b, g, sb))
         print(f"gram {ma}x{mb} g={g} {H}x{W} sum_batch={int(sb)}: {us:8.1f} us {(a.numel() + b.numel()) * 2 / us / 1e3:7.0f} GB/s",
               flush=True)
+        if not sb:
+            us = timeit(lambda: ops.gram(a, b, g, False, True))
+            print(f"gram+sumsq {ma}x{mb} g={g} {H}x{W}: {us:8.1f} us {(a.numel() + b.numel()) * 2 / us / 1e3:7.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
