@@ -84,9 +84,11 @@ def pmc_traffic(kernel: str):
         return None
     with open(path) as f:
         table = json.load(f)
+    import re
+    pat = re.compile(rf"{re.escape(kernel)}(_res|_dma|_stream|_wave)?_kernel")   # every variant booked under this profiler key
     tot = n = 0.0
     for name, row in table.items():
-        if f"{kernel}_kernel" in name:
+        if pat.search(name):
             tot += row["hbm_bytes_per_launch"] * row["launches"]
             n += row["launches"]
     return round(tot / n) if n else None
