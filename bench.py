@@ -216,16 +216,19 @@ def main():
     value = pixels / elapsed / 1e6
 
     roofline = None
-    if not args.no_roofline and rank == 0:
-        # profiled pass: same workload, eager, every kernel bracketed by HIP events on its own stream
+    nprof = 2
+    if not args.no_roofline:
+        # profiled pass: same workload, eager, every kernel bracketed by HIP events on its own stream.  EVERY rank runs
+        # these steps (they contain the gradient all-reduce); only rank 0 records and reports.
         step_e, _ = make_step(model, trainer, noisy, clean, use_dev_scalars=False)
         step_e()
         torch.cuda.synchronize()
-        ops.prof_enable(True)
-        nprof = 2
+        if rank == 0:
+            ops.prof_enable(True)
         for _ in range(nprof):
             step_e()
         torch.cuda.synchronize()
+    if not args.no_roofline and rank == 0:
         table = ops.prof_collect()
         ops.prof_enable(False)
         tot_ms = sum(v["ms"] for v in table.values())
