@@ -134,6 +134,11 @@ def main():
     torch.cuda.set_device(dev)
 
     import __graft_entry__ as entry
+    if world > 1:
+        # one rank runs make (the others would race it on the same object files), everybody loads the result
+        if rank == 0:
+            entry.build()
+        dist.barrier()
     entry.build()
     import image_restoration_amd as m
     from image_restoration_amd import ops
