@@ -243,3 +243,37 @@ def test_thin_glue_conv3x3_native(dtype, tol, cin, cout, hw, bias):
     assert rel(conv.weight.grad, wr.grad) < tol
     if bias:
         assert rel(conv.bias.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("c,heads,hw", [(48, 1, (256, 256)), (96, 1, (256, 256)), (96, 2, (128, 128)), (192, 4, (64, 64)),
+                                        (384, 8, (32, 32))])
+def test_block_at_training_resolution_vs_oracle(dtype, tol, c, heads, hw):
+    """Every level of Restormer base at its REAL plane size for 256x256 training (BASELINE configs 1-2: level 1 and
+    decoder/refinement at 256^2, level 2 at 128^2, level 3 at 64^2, latent at 32^2), two images, forward and all gradients
+    against the oracle (fp32 on the host: fp64 at these sizes would take minutes).  This is where the full-width streaming
+    depthwise kernels (64 lanes per row), the weight-resident GEMM, the streaming Gram with many pixel splits and the
+    wave-owned LayerNorms actually run; the small-shape tests above cannot reach them."""
+    m = M()
+    H, W = hw
+    shape = (2, c, H, W)
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=c + 7 * heads)
+    blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias")
+    blk.load_state_dict(sd)
+    x = seeded_input(shape, 960 + c)
+    cot = seeded_input(shape, 961 + c)
+    if dtype == torch.bfloat16:
+        x, cot = x.bfloat16().float(), cot.bfloat16().float()
+    y, dx, g = run(blk, x, cot, dtype)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1) or 1)
+    xr = x.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = R.transformer_block(xr, sdr, heads, "WithBias")
+    yr.backward(cot)
+    assert rel(y, yr) < tol
+    assert rel(dx, xr.grad) < tol
+    for k, v in g.items():
+        # the temperature gradient of a normalised-logit softmax is a small difference of large sums over 65536 pixels:
+        # fp32 host arithmetic itself is only good to ~1e-3 there
+        bound = 10 * tol if k.endswith("temperature") else tol
+        assert rel(v, sdr[k].grad) < bound, k
