@@ -113,9 +113,19 @@ template <typename T, bool DMA> struct PwXAddr {
   }
 };
 
+// Which 16-channel fragments of a TM-row tile a wave owns.  TM = 64 MF splits evenly (MF each); TM = 96 gives the four
+// waves 2, 2, 1, 1 fragments and TM = 48 gives 1, 1, 1, 0: a 96- or 48-channel matrix then stages, multiplies and stores 25%
+// less than when padded to 128 / 64 (these kernels are instruction-issue-bound, profiles/r01_x_pmc_pw_gemm_bs32.txt).
+template <int MF, int TM> __device__ __forceinline__ void pw_wave_rows(int wv, int& mw, int& nfr) {
+  if (TM == 64 * MF) { mw = wv * MF * 16; nfr = MF; }
+  else if (TM == 96) { mw = wv < 2 ? wv * 32 : 64 + (wv - 2) * 16; nfr = wv < 2 ? 2 : 1; }
+  else { mw = wv < 3 ? wv * 16 : 0; nfr = wv < 3 ? 1 : 0; }   // TM == 48 (the idle wave points at valid rows)
+}
+
 // one 32-deep chunk of MFMAs: acc[nf][mf] += X^T(pixels 16nf.., k) * W^T(k, channels mw+16mf..)
 template <typename T, int MF, bool DMA, int XS = PW_XS>
-__device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*acc)[MF], int mw, int li, int g) {
+__device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*acc)[MF], int mw, int li, int g,
+                                             int nfr = MF) {
   constexpr bool F32 = std::is_same<T, float>::value;
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
   struct XA {
@@ -129,12 +139,12 @@ __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*a
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) a[nf] = Xs[XA::at(kk, 16 * nf + li)];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) b[mf] = Ws[(mw + 16 * mf + li) * WS_ROW + kk];
+      for (int mf = 0; mf < MF; ++mf) b[mf] = mf < nfr ? Ws[(mw + 16 * mf + li) * WS_ROW + kk] : 0.f;
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
+          if (mf < nfr) acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
     }
   } else {
     // k slots: element j<4 of lane group g is k = 4g+j, element j>=4 is k = 16+4g+(j-4), for A and B alike.
@@ -149,7 +159,7 @@ __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*a
     }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const T* wr = &Ws[(mw + 16 * mf + li) * WS_ROW + 4 * g];
+      const T* wr = &Ws[(mw + 16 * (mf < nfr ? mf : 0) + li) * WS_ROW + 4 * g];   // (an unowned fragment re-reads an owned row)
       blo[mf] = *reinterpret_cast<const s16x4*>(wr);
       bhi[mf] = *reinterpret_cast<const s16x4*>(wr + 16);
     }
@@ -167,7 +177,7 @@ __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*a
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
-        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
+        if (mf < nfr) acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b[mf], acc[nf][mf], 0, 0, 0);
   }
 }
 
@@ -176,7 +186,7 @@ __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*a
 // store) and written as whole 128-byte row segments, 16 bytes per lane, with bias and residual added on the way.
 template <typename T, int MF>
 __device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const f32x4 (*acc)[MF], int zb, int zg, int m0,
-                                            int64_t n0, int mw, int lane, int wv) {
+                                            int64_t n0, int mw, int lane, int wv, int nfr = MF) {
   constexpr bool F32 = std::is_same<T, float>::value;
   const int li = lane & 15, g = lane >> 4;
   T* yz = (T*)p.y + zb * p.y_bs + zg * p.y_gs;
@@ -190,10 +200,11 @@ __device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const 
   __syncthreads();                        // every wave is done reading the last chunk
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
+    const bool own = mf < nfr;            // wave-uniform; a wave without this fragment only keeps the barriers company
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       float o[4] = {acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]};
-      Vec<float, 4>::st(&slab[li * OS + 16 * nf + 4 * g], o);
+      if (own) Vec<float, 4>::st(&slab[li * OS + 16 * nf + 4 * g], o);
     }
     __syncthreads();
 #pragma unroll
@@ -201,7 +212,7 @@ __device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const 
       const int row = it * RPI + lane / LPR, col = (lane % LPR) * EPV;
       const int m = m0 + mw + 16 * mf + row;
       const int64_t n = n0 + col;
-      if (m < p.m && n < p.n) {
+      if (own && m < p.m && n < p.n) {
         float o[EPV];
 #pragma unroll
         for (int v = 0; v < EPV / 4; ++v) Vec<float, 4>::ld(&slab[row * OS + col + 4 * v], o + 4 * v);
@@ -231,11 +242,10 @@ __device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const 
 constexpr int PW_SLAB_BYTES = 4 * 16 * (PW_TN + 4) * (int)sizeof(float);  // epilogue: 4 waves x 16 rows x fp32
 
 // ---- register-staged form: any alignment / ragged pixel counts; one chunk of prefetch ----
-template <typename T, int MF>
+template <typename T, int MF, int TM = 64 * MF>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
   const PwK& p = q.k;
   constexpr bool F32 = std::is_same<T, float>::value;
-  constexpr int TM = 64 * MF;
   using IM = PwImg<T, TM>;
   constexpr int X_ELEMS = PW_KC * PW_XS, W_ELEMS = TM * IM::WS_ROW;
   constexpr int STAGE_BYTES = (X_ELEMS + W_ELEMS) * (int)sizeof(T);
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int mw = wv * MF * 16;  // this wave's first m inside the tile
+  int mw, nfr;                  // this wave's first m inside the tile, and how many 16-row fragments it owns
+  pw_wave_rows<MF, TM>(wv, mw, nfr);
 
   load_stage(0);
   for (int c = 0; c < nchunks; ++c) {
@@ -314,9 +325,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
     write_stage();
     __syncthreads();
     if (c + 1 < nchunks) load_stage(c + 1);
-    pw_chunk_mma<T, MF, false>(Xs, Ws, acc, mw, li, g);
+    pw_chunk_mma<T, MF, false>(Xs, Ws, acc, mw, li, g, nfr);
   }
-  pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_raw), acc, zb, zg, m0, n0, mw, lane, wv);
+  pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_raw), acc, zb, zg, m0, n0, mw, lane, wv, nfr);
 }
 
 // ---- weight-resident form (bf16, K <= 128, vector-aligned) ------------------------------------------------------------------
@@ -327,11 +338,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
 // pixel tiles: ALL K chunks of the next tile's X and the residual of the current one are loaded into registers while the
 // current tile is multiplied, so a tile costs one exposed round trip at most, three barriers, and no weight traffic.
 constexpr int PWR_MAXC = 4;                                       // K chunks held (K <= 128)
-template <int MF>
+template <int MF, int TM = 64 * MF>
 __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, int chunk_stride_elems) {
   using T = bf16;
   const PwK& p = q.k;
-  constexpr int TM = 64 * MF;
   constexpr int WS_ROW = PwRow<T>::WS_ROW;
   constexpr int WC_ELEMS = TM * WS_ROW;                           // one weight chunk in LDS (packed back to back)
   constexpr int XC_ELEMS = PW_KC * PW_XS;                         // one X chunk
@@ -347,7 +357,8 @@ __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, in
   const int li = lane & 15, g = lane >> 4;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int m0 = blockIdx.y * TM;
-  const int mw = wv * MF * 16;
+  int mw, nfr;
+  pw_wave_rows<MF, TM>(wv, mw, nfr);
   const int ktot = p.k1 + p.k2;
   {  // weight image: straight 16-byte copies from the packed workspace / cache
     const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, in
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int m = m0 + mw + 16 * mf + it * 8 + e_row;
-        r[mf][it] = (rz && tile < n_tiles && m < p.m && n < p.n) ? *reinterpret_cast<const u32x4*>(rz + (int64_t)m * p.n + n) : zero4;
+        r[mf][it] = (rz && mf < nfr && tile < n_tiles && m < p.m && n < p.n) ? *reinterpret_cast<const u32x4*>(rz + (int64_t)m * p.n + n) : zero4;
       }
   };
 
@@ -405,11 +416,12 @@ __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, in
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < MF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunks; ++c) pw_chunk_mma<T, MF, false>(Xl + c * XC_ELEMS, Wl + c * WC_ELEMS, acc, mw, li, g);
+    for (int c = 0; c < nchunks; ++c) pw_chunk_mma<T, MF, false>(Xl + c * XC_ELEMS, Wl + c * WC_ELEMS, acc, mw, li, g, nfr);
     __syncthreads();                                   // everyone is done reading X: the slabs may overwrite it
     const int64_t n0 = (int64_t)tile * PW_TN;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
+      if (mf >= nfr) continue;                         // wave-uniform: this wave does not own a second fragment
       wave_lds_sync();
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) {
@@ -534,8 +546,24 @@ static PwPlan pw_plan(const mi_pw_desc* d) {
   PwPlan pl;
   // m-tile 128 when its padding stays within 25% of the 64-granular minimum, else 64.  (256-row tiles measured 5-8%
   // slower on the wide GDFN shapes: fewer resident workgroups; profiles/r01_n_pw_tile_staging_ab.log)
-  const int mmin = cdiv(d->m, 64) * 64;
-  pl.tm = (cdiv(d->m, 128) * 128 * 4 <= mmin * 5) ? 128 : 64;
+  // m-tile: every m-tile streams all of X again and writes its (padded) rows of Y, so the rows moved per pixel are
+  // m_tiles * (K + tm); 96- and 48-row tiles keep 96- / 48- / 144- / 288-channel matrices from being padded by a third
+  // (ties go to the larger tile; the LDS-DMA kernel only has 64 / 128).
+  {
+    const bool dma = getenv("MI_PW_DMA") != nullptr || getenv("MI_PW_TM_EVEN") != nullptr;   // (the latter: A/B switch)
+    const int ktot = d->k1 + d->k2;
+    int64_t best_cost = 0;
+    pl.tm = 0;
+    for (int tm : {128, 96, 64, 48}) {
+      if (dma && (tm == 96 || tm == 48)) continue;
+      // the uneven tiles only where they fit exactly (M = 48 / 96 / 288): a half-empty 96-row tile measured slower than
+      // the 64-row tiling it would replace (M = 144: 291 vs 268 us; profiles/r01_zz_pw_tm96_bs32.log)
+      if (tm == 96 && !(d->m <= 96 || d->m % 96 == 0)) continue;
+      if (tm == 48 && d->m > 48) continue;
+      const int64_t cost = (int64_t)cdiv(d->m, tm) * (ktot + tm);
+      if (!pl.tm || cost < best_cost) { pl.tm = tm; best_cost = cost; }
+    }
+  }
   pl.m_tiles = cdiv(d->m, pl.tm);
   pl.k_chunks = cdiv(d->k1 + d->k2, PW_KC);
   pl.per_batch = d->w_bs != 0;
@@ -652,14 +680,20 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     if (tpb > 32) tpb = 32;
     dim3 rgrid((unsigned)cdiv(n_tiles, tpb), pl.m_tiles, grid.z);
     if (pl.tm == 128) {
-      if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_res_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((pw_gemm_res_kernel<2>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
+      if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_res_kernel<2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((pw_gemm_res_kernel<2, 128>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
+    } else if (pl.tm == 96) {
+      hipLaunchKernelGGL((pw_gemm_res_kernel<2, 96>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
+    } else if (pl.tm == 64) {
+      hipLaunchKernelGGL((pw_gemm_res_kernel<1, 64>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
     } else {
-      hipLaunchKernelGGL((pw_gemm_res_kernel<1>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
+      hipLaunchKernelGGL((pw_gemm_res_kernel<1, 48>), rgrid, block, lds, st, q, n_tiles, pl.chunk_elems);
     }
   } else {
-    if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2>), grid, block, 0, st, q);
-    else hipLaunchKernelGGL((pw_gemm_kernel<T, 1>), grid, block, 0, st, q);
+    if (pl.tm == 128) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, 128>), grid, block, 0, st, q);
+    else if (pl.tm == 96) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, 96>), grid, block, 0, st, q);
+    else if (pl.tm == 64) hipLaunchKernelGGL((pw_gemm_kernel<T, 1, 64>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((pw_gemm_kernel<T, 1, 48>), grid, block, 0, st, q);
   }
   MI_LAUNCH_CHECK();
   return MI_OK;
