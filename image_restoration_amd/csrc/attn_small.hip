@@ -21,18 +21,35 @@ static inline int attn_ct(int c) { return (c + 15) / 16; }
 static inline int attn_rchunks(int C) { return (C + ATT_RC - 1) / ATT_RC; }
 
 // cosine, temperature, row softmax of one (image, head) into LDS As[c][ld]; optionally stored to global P/A/nrm
+// (All global reads of a thread are issued before the first is used: written as `for (e = t; e < c*c; e += 256)` the
+// loop took one HBM/L2 round trip per element - 36 in a row at c = 96 - and these kernels ran 40-70 us on KB-sized data.)
+template <int CT>
 __device__ __forceinline__ void attn_softmax_to_lds(float* As, int ld, const float* __restrict__ gz,
                                                     const float* __restrict__ sz, float temp, int c, float* P, float* A,
                                                     float* nrm) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (nrm)
     for (int e = t; e < 2 * c; e += 256) nrm[e] = fmaxf(sqrtf(sz[e]), NORM_EPS);
-  for (int e = t; e < c * c; e += 256) {
-    const int i = e / c, j = e - i * c;
-    const float nq = fmaxf(sqrtf(sz[i]), NORM_EPS), nk = fmaxf(sqrtf(sz[c + j]), NORM_EPS);
-    const float pv = gz[e] / (nq * nk);
-    if (P) P[e] = pv;
-    As[i * ld + j] = pv * temp;
+  float gv[CT * CT], sq[CT * CT], sk[CT * CT];
+#pragma unroll
+  for (int it = 0; it < CT * CT; ++it) {
+    const int e = t + 256 * it;
+    const bool in = e < c * c;
+    const int i = in ? e / c : 0, j = in ? e - i * c : 0;
+    gv[it] = in ? gz[e] : 0.f;
+    sq[it] = sz[i];
+    sk[it] = sz[c + j];
+  }
+#pragma unroll
+  for (int it = 0; it < CT * CT; ++it) {
+    const int e = t + 256 * it;
+    if (e < c * c) {
+      const int i = e / c, j = e - i * c;
+      const float nq = fmaxf(sqrtf(sq[it]), NORM_EPS), nk = fmaxf(sqrtf(sk[it]), NORM_EPS);
+      const float pv = gv[it] / (nq * nk);
+      if (P) P[e] = pv;
+      As[i * ld + j] = pv * temp;
+    }
   }
   __syncthreads();
   for (int i = wv; i < c; i += 4) {
@@ -70,17 +87,28 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
   const int z = blockIdx.x, b = z / heads, h = z - b * heads;
   const int r0 = blockIdx.y * ATT_RC;
   const int t = threadIdx.x, tr = t >> 4, tj = t & 15;
-  for (int e = t; e < ATT_RC * c; e += 256) {
-    const int rr = e / c, col = e - rr * c;
-    Wt[e] = r0 + rr < C ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+  {
+    float wv_[CT];
+#pragma unroll
+    for (int it = 0; it < CT; ++it) {
+      const int e = t + 256 * it;
+      const int rr = e / c, col = e - rr * c;
+      wv_[it] = (e < ATT_RC * c && r0 + rr < C) ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < CT; ++it) {
+      const int e = t + 256 * it;
+      if (e < ATT_RC * c) Wt[e] = wv_[it];
+    }
   }
   const bool first = blockIdx.y == 0;
-  attn_softmax_to_lds(As, ld, graw + (int64_t)z * c * c, ss + (int64_t)z * 2 * c, temperature[h], c,
+  attn_softmax_to_lds<CT>(As, ld, graw + (int64_t)z * c * c, ss + (int64_t)z * 2 * c, temperature[h], c,
                       first ? P + (int64_t)z * c * c : nullptr, first ? A + (int64_t)z * c * c : nullptr,
                       first ? nrm + (int64_t)z * 2 * c : nullptr);
   float acc[CT];
 #pragma unroll
   for (int q = 0; q < CT; ++q) acc[q] = 0.f;
+#pragma unroll 4
   for (int i = 0; i < c; ++i) {
     const float w = Wt[tr * c + i];
 #pragma unroll
@@ -116,13 +144,32 @@ __global__ __launch_bounds__(256) void attn_bwd_partial_kernel(const float* __re
   const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
   const float* dMb = dM + (int64_t)b * C * C;
   const float* Az = A + (int64_t)z * c * c;
-  for (int e = t; e < ATT_RC * c; e += 256) {
-    const int rr = e / c, col = e - rr * c;
-    const bool in = r0 + rr < C;
-    Wt[e] = in ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
-    Dt[e] = in ? dMb[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+  {
+    float wv_[CT], dv_[CT], av_[CT * CT];
+#pragma unroll
+    for (int it = 0; it < CT; ++it) {
+      const int e = t + 256 * it;
+      const int rr = e / c, col = e - rr * c;
+      const bool in = e < ATT_RC * c && r0 + rr < C;
+      wv_[it] = in ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+      dv_[it] = in ? dMb[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < CT * CT; ++it) {
+      const int e = t + 256 * it;
+      av_[it] = e < c * c ? Az[e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < CT; ++it) {
+      const int e = t + 256 * it;
+      if (e < ATT_RC * c) { Wt[e] = wv_[it]; Dt[e] = dv_[it]; }
+    }
+#pragma unroll
+    for (int it = 0; it < CT * CT; ++it) {
+      const int e = t + 256 * it;
+      if (e < c * c) { const int i = e / c; As[i * ld + (e - i * c)] = av_[it]; }
+    }
   }
-  for (int e = t; e < c * c; e += 256) { const int i = e / c; As[i * ld + (e - i * c)] = Az[e]; }
   __syncthreads();
   float acc[CT][CT];
 #pragma unroll
@@ -201,14 +248,33 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
       acc[a][q] = 0.f;
       av[a][q] = (i < c && j < c) ? Az[i * c + j] : 0.f;
     }
-  for (int rc = 0; rc < rchunks; ++rc) {
+  float pvv[CT][CT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int i = ti + 16 * a, j = tj + 16 * q;
+      pvv[a][q] = (i < c && j < c) ? Pz[i * c + j] : 0.f;
+    }
+  // four chunk partials per step: their loads are independent and go out together (one round trip per four chunks)
+  for (int rc = 0; rc < rchunks; rc += 4) {
+    float t0[CT][CT], t1[CT][CT], t2[CT][CT], t3[CT][CT];
 #pragma unroll
     for (int a = 0; a < CT; ++a)
 #pragma unroll
       for (int q = 0; q < CT; ++q) {
         const int i = ti + 16 * a, j = tj + 16 * q;
-        if (i < c && j < c) acc[a][q] += dAz[(int64_t)rc * c * c + i * c + j];
+        const bool in = i < c && j < c;
+        const int64_t o = (int64_t)rc * c * c + i * c + j;
+        t0[a][q] = in ? dAz[o] : 0.f;
+        t1[a][q] = (in && rc + 1 < rchunks) ? dAz[o + (int64_t)c * c] : 0.f;
+        t2[a][q] = (in && rc + 2 < rchunks) ? dAz[o + 2 * (int64_t)c * c] : 0.f;
+        t3[a][q] = (in && rc + 3 < rchunks) ? dAz[o + 3 * (int64_t)c * c] : 0.f;
       }
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+      for (int q = 0; q < CT; ++q) acc[a][q] += ((t0[a][q] + t1[a][q]) + t2[a][q]) + t3[a][q];
   }
   float tsum = 0.f;
   float colsum[CT];
@@ -229,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
       float ds = 0.f;
       if (i < c && j < c) {
         ds = av[a][q] * (acc[a][q] - dot);
-        const float pv = Pz[i * c + j];
+        const float pv = pvv[a][q];
         tsum += ds * pv;
         rqa += ds * pv * temp;
         colsum[q] += ds * pv * temp;

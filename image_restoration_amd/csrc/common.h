@@ -162,10 +162,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 #undef MI_DPP_ADD
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float wave_max(float v) {   // same DPP ladder as wave_sum (no LDS-pipe ds_bpermute round trips)
+#define MI_DPP_MAX(ctrl, rmask)                                                                                    \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                     ctrl, rmask, 0xf, false)))
+  MI_DPP_MAX(0x111, 0xf);
+  MI_DPP_MAX(0x112, 0xf);
+  MI_DPP_MAX(0x114, 0xf);
+  MI_DPP_MAX(0x118, 0xf);
+  MI_DPP_MAX(0x142, 0xa);
+  MI_DPP_MAX(0x143, 0xc);
+#undef MI_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // erf-form GELU and its derivative (Restormer.py:91: F.gelu default = erf form).
