@@ -277,3 +277,27 @@ def test_block_at_training_resolution_vs_oracle(dtype, tol, c, heads, hw):
         # fp32 host arithmetic itself is only good to ~1e-3 there
         bound = 10 * tol if k.endswith("temperature") else tol
         assert rel(v, sdr[k].grad) < bound, k
+
+
+@pytest.mark.parametrize("env", ["MI_GRAM_LDS", "MI_GRAM_STREAM_ALL", "MI_PW_CHUNKED", "MI_PW_TM_EVEN", "MI_DW_LDS",
+                                 "MI_GDFN_STORE_Y", "MI_LN_FORM=block", "MI_LN_FORM=wave", "MI_PW_DMA"])
+def test_alternate_kernel_paths_stay_correct(monkeypatch, env):
+    """Every A/B switch selects a kernel that is otherwise only reached for other shapes (or not at all): run one block
+    at a training-size plane through each and hold it to the same bound as the default path."""
+    name, _, val = env.partition("=")
+    monkeypatch.setenv(name, val or "1")
+    m = M()
+    c, heads, shape = 96, 2, (2, 96, 64, 128)
+    sd = R.make_block_state(c, heads, 2.66, True, "WithBias", seed=77)
+    blk = m.TransformerBlock(c, heads, 2.66, True, "WithBias")
+    blk.load_state_dict(sd)
+    x, cot = seeded_input(shape, 970), seeded_input(shape, 971)
+    y, dx, g = run(blk, x, cot)
+    xr = x.clone().requires_grad_(True)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = R.transformer_block(xr, sdr, heads, "WithBias")
+    yr.backward(cot)
+    assert rel(y, yr) < 2e-4
+    assert rel(dx, xr.grad) < 2e-4
+    for k, v in g.items():
+        assert rel(v, sdr[k].grad) < (2e-3 if k.endswith("temperature") else 2e-4), k
