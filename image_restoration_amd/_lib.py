@@ -121,6 +121,11 @@ SIGNATURES = {
                               vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, fp, vp]),
+    "mi_rows_gather": (C.c_int, [vp, vp, vp, C.c_int, c_i64, C.c_int, vp]),
+    "mi_rows_gather_scaled": (C.c_int, [fp, vp, fp, vp, C.c_int, c_i64, C.c_int, vp]),
+    "mi_rows_scatter_add": (C.c_int, [vp, vp, fp, vp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "mi_rows_dot_workspace": (C.c_size_t, [C.c_int, c_i64]),
+    "mi_rows_dot": (C.c_int, [fp, vp, vp, fp, C.c_int, c_i64, C.c_int, vp, vp]),
     "mi_glue3x3_ok": (C.c_int, [C.c_int, C.c_int]),
     "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

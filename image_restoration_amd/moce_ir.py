@@ -7,7 +7,7 @@ global average pool.  Still PyTorch-ROCm ops this round ("next")
 ``FFTAttention`` and the [B, E] scalar math of the router (softmax / top-k / CV^2 losses).
 
 ``AdapterLayer`` keeps the reference's data flow (per-expert ragged sub-batches through ``SparseDispatcher``, one host
-sync per call as in moce_ir.py:88) because the expert bodies need real sub-batches while they run as torch ops.
+sync per call as in moce_ir.py:88); the dispatcher's gather and gate-weighted scatter-add run as native row kernels.
 """
 from __future__ import annotations
 
@@ -47,6 +47,40 @@ class _GapFn(torch.autograd.Function):
         return ops.gap_bwd(dout, x)
 
 
+class _RowsGatherFn(torch.autograd.Function):
+    """dispatch: out[i] = x[idx[i]] over whole feature maps; backward scatters the gradients back per sample."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_rows = x.shape[0]
+        return ops.rows_gather(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return ops.rows_scatter_add(dout.contiguous(), idx, None, ctx.n_rows, out_f32=False), None
+
+
+class _RowsCombineFn(torch.autograd.Function):
+    """combine: out[b] = sum_{i: idx[i]==b} gate[i] * src[i] in fp32 (moce_ir.py:116-124)."""
+
+    @staticmethod
+    def forward(ctx, src, gates, idx, n_rows):
+        src = src.contiguous()
+        gates = gates.reshape(-1).float().contiguous() if gates is not None else None
+        ctx.save_for_backward(src, gates, idx)
+        return ops.rows_scatter_add(src, idx, gates, n_rows, out_f32=True)
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, gates, idx = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        dsrc = ops.rows_gather_scaled(dout, idx, gates, src.dtype)
+        dgates = ops.rows_dot(dout, src, idx).reshape(-1, 1) if (gates is not None and ctx.needs_input_grad[1]) else None
+        return dsrc, dgates, None, None
+
+
 class SparseDispatcher(object):
     """Sample -> expert bookkeeping with the reference's API (moce_ir.py:71-143): ``dispatch`` gathers the rows of the
     batch routed to each expert, ``combine`` scatters the gate-weighted expert outputs back (fp32 accumulation)."""
@@ -63,11 +97,19 @@ class SparseDispatcher(object):
         self._nonzero_gates = torch.gather(gates_exp, 1, self._expert_index)
 
     def dispatch(self, inp):
-        inp_exp = inp[self._batch_index].squeeze(1)
+        idx = self._batch_index.flatten()
+        if inp.is_cuda and inp.dim() == 4 and inp.dtype in (torch.float32, torch.bfloat16):
+            inp_exp = _RowsGatherFn.apply(inp, idx)                      # native row gather (csrc/dispatch.hip)
+        else:
+            inp_exp = inp[self._batch_index].squeeze(1)
         return torch.split(inp_exp, self._part_sizes, dim=0)
 
     def combine(self, expert_out, multiply_by_gates=True):
         stitched = torch.cat(expert_out, 0)
+        if stitched.is_cuda and stitched.dim() == 4 and stitched.dtype in (torch.float32, torch.bfloat16):
+            # gate multiply + index_add into fp32 zeros in one deterministic scatter (moce_ir.py:118-124)
+            return _RowsCombineFn.apply(stitched, self._nonzero_gates if multiply_by_gates else None,
+                                        self._batch_index.flatten(), self._gates.size(0))
         if multiply_by_gates:
             stitched = stitched.mul(self._nonzero_gates.unsqueeze(-1).unsqueeze(-1))
         zeros = torch.zeros(self._gates.size(0), expert_out[-1].size(1), expert_out[-1].size(2), expert_out[-1].size(3),

@@ -326,6 +326,52 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
 
 
 # ----------------------------------------------------------------------------- router GAP
+def rows_gather(x: Tensor, idx: Tensor) -> Tensor:
+    """out[i] = x[idx[i]] over whole [C,H,W] rows (SparseDispatcher.dispatch)."""
+    _gpu(x, idx)
+    assert idx.dtype == torch.int64 and x.is_contiguous()
+    n = int(idx.numel())
+    out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    row = x[0].numel()
+    L.check(L.lib().mi_rows_gather(_p(x), _p(idx), _p(out), n, row, _dt(x), _stream()), "rows_gather")
+    return out
+
+
+def rows_gather_scaled(x_f32: Tensor, idx: Tensor, scale: Optional[Tensor], dtype: torch.dtype) -> Tensor:
+    """out[i] = scale[i] * x_f32[idx[i]] cast to `dtype`."""
+    _gpu(x_f32, idx, scale)
+    assert x_f32.dtype == torch.float32 and idx.dtype == torch.int64 and x_f32.is_contiguous()
+    n = int(idx.numel())
+    out = torch.empty((n,) + tuple(x_f32.shape[1:]), dtype=dtype, device=x_f32.device)
+    L.check(L.lib().mi_rows_gather_scaled(_p(x_f32), _p(idx), _p(_f32(scale, "scale")), _p(out), n, x_f32[0].numel(),
+                                          L.MI_BF16 if dtype == torch.bfloat16 else L.MI_F32, _stream()), "rows_gather_scaled")
+    return out
+
+
+def rows_scatter_add(src: Tensor, idx: Tensor, scale: Optional[Tensor], n_rows: int, out_f32: bool) -> Tensor:
+    """out[b] = sum_{i: idx[i]==b} scale[i] * src[i], accumulated in fp32 (SparseDispatcher.combine)."""
+    _gpu(src, idx, scale)
+    assert idx.dtype == torch.int64 and src.is_contiguous()
+    out = torch.empty((n_rows,) + tuple(src.shape[1:]), dtype=torch.float32 if out_f32 else src.dtype, device=src.device)
+    row = src[0].numel() if src.shape[0] else out[0].numel()
+    L.check(L.lib().mi_rows_scatter_add(_p(src), _p(idx), _p(_f32(scale, "scale")), _p(out), int(src.shape[0]), n_rows, row,
+                                        _dt(src), 1 if out_f32 else 0, _stream()), "rows_scatter_add")
+    return out
+
+
+def rows_dot(g: Tensor, src: Tensor, idx: Tensor) -> Tensor:
+    """out[i] = <g[idx[i]], src[i]> (fp32 g): gradient of the combine's gate values."""
+    _gpu(g, src, idx)
+    n = int(src.shape[0])
+    out = torch.zeros(n, dtype=torch.float32, device=src.device)
+    if n == 0:
+        return out
+    row = src[0].numel()
+    ws = _blob(L.lib().mi_rows_dot_workspace(n, row), src.device)
+    L.check(L.lib().mi_rows_dot(_p(_f32(g, "g")), _p(src), _p(idx), _p(out), n, row, _dt(src), _p(ws), _stream()), "rows_dot")
+    return out
+
+
 def glue3x3_ok(H: int, W: int) -> bool:
     return bool(L.lib().mi_glue3x3_ok(H, W))
 

@@ -233,6 +233,25 @@ int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   const float* dev_scalars, void* stream);
 
 /* ------------------------------------------------------------------------
+ * MoCE SparseDispatcher data movement (moce_ir.py:71-143).  A "row" is one sample's feature map (C*H*W elements);
+ * idx is the dispatcher's _batch_index (int64, device), scale its _nonzero_gates (fp32, device).
+ *   rows_gather      : out[i] = x[idx[i]]                                    (dispatch, :103)
+ *   rows_scatter_add : out[b] = sum_{i: idx[i]==b} scale[i] * src[i]          (combine: gate multiply + index_add into
+ *                      zeros, fp32 accumulation, :116-124; scale NULL = 1; out is fp32 or the activation dtype)
+ *   rows_gather_scaled: out[i] = scale[i] * x[idx[i]], fp32 x -> activation dtype (gradient of combine w.r.t. expert outputs)
+ *   rows_dot         : out[i] = <g[idx[i]], src[i]>                           (gradient of the gate values)
+ * The scatter is per destination row in list order: deterministic, no atomics.
+ * ------------------------------------------------------------------------ */
+int mi_rows_gather(const void* x, const int64_t* idx, void* out, int n_out, int64_t row, int dtype, void* stream);
+int mi_rows_gather_scaled(const float* x, const int64_t* idx, const float* scale, void* out, int n_out, int64_t row,
+                          int out_dtype, void* stream);
+int mi_rows_scatter_add(const void* src, const int64_t* idx, const float* scale, void* out, int n_src, int n_rows,
+                        int64_t row, int dtype, int out_f32, void* stream);
+size_t mi_rows_dot_workspace(int n_src, int64_t row);
+int mi_rows_dot(const float* g, const void* src, const int64_t* idx, float* out, int n_src, int64_t row, int dtype,
+                void* ws, void* stream);
+
+/* ------------------------------------------------------------------------
  * U-Net glue, thin dense 3x3 convolutions (Restormer.py:156-165 OverlapPatchEmbed 3->48; :243,281 output conv 2*dim->3
  * + input residual).  Layout kernels that turn them into the 1x1 GEMM / Gram above:
  *   im2col3x3: x[B,C,H,W] -> col[B,9C,H,W], col[c*9+ky*3+kx][y][x] = x[c][y+ky-1][x+kx-1] (zero padded);
