@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void dws_gate_fwd2_kernel(DwArgs a, int planes
 // rows per band: tall bands amortise the two halo rows; short ones keep >= ~8 waves per SIMD on small launches
 static int pick_band(int H, int64_t planes, int lpr) {
   const int G = 64 / lpr;
-  for (int band : {32, 16}) {
+  for (int band : {64, 32, 16}) {
     const int64_t waves = planes * cdiv(H, band) / G;
     if (waves >= 8192) return band;
   }
