@@ -103,6 +103,93 @@ __global__ __launch_bounds__(64 * MW) void dw_blocked_kernel(const bf16_t* __res
   }
 }
 
+// ---- v2: 4 channels per lane (8-byte loads, lane = 8 pixels x 8 channel groups = 512 contiguous bytes per wave load), scatter form:
+// an arriving input row is unpacked once and added into the three output rows it touches (three fp32 accumulator rows instead of a
+// three-row input window), packed fp32 FMAs, 36 weight registers per lane.  SW strips of 8 pixels per wave side by side.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+struct Raw3 { u32x2 l, c, r; };
+// always-executed loads from clamped addresses (no divergent branch around a load, so the compiler can count them in s_waitcnt);
+// out-of-image taps are zeroed when the row is consumed
+__device__ inline Raw3 load_raw3(const bf16_t* plane, int y, int x, int H, int W, int cg) {
+  Raw3 o;
+  const int yc = min(max(y, 0), H - 1);
+  const bf16_t* p = plane + ((long)yc * W + x) * 32 + 4 * cg;
+  o.c = *reinterpret_cast<const u32x2*>(p);
+  o.l = *reinterpret_cast<const u32x2*>(x > 0 ? p - 32 : p);
+  o.r = *reinterpret_cast<const u32x2*>(x + 1 < W ? p + 32 : p);
+  return o;
+}
+__device__ inline Raw3 mask_raw3(Raw3 o, int y, int x, int H, int W) {
+  const bool row = y >= 0 && y < H;
+  const unsigned mc = row ? ~0u : 0u, ml = (row && x > 0) ? ~0u : 0u, mr = (row && x + 1 < W) ? ~0u : 0u;
+  o.c[0] &= mc; o.c[1] &= mc; o.l[0] &= ml; o.l[1] &= ml; o.r[0] &= mr; o.r[1] &= mr;
+  return o;
+}
+__device__ inline f32x2 up(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+
+template <int MW, int SW>
+__global__ __launch_bounds__(64 * MW) void dw_blocked4_kernel(const bf16_t* __restrict__ X, const float* __restrict__ Wt, bf16_t* __restrict__ Y,
+                                                              int C, int H, int W, int band) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int px = lane >> 3, cg = lane & 7;
+  const int strips = W / (8 * SW);
+  const int unit = blockIdx.x * MW + wv;
+  const int strip = unit % strips, y0 = (unit / strips) * band;
+  if (y0 >= H) return;
+  const int cb = blockIdx.y, z = blockIdx.z;
+  const long plane_off = ((long)z * (C / 32) + cb) * (long)H * W * 32;
+  const bf16_t* xp = X + plane_off;
+  bf16_t* yp = Y + plane_off;
+  const int x0 = strip * 8 * SW + px;
+  f32x2 w[9][2];                      // taps x channel pairs
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      w[k][j] = (f32x2){Wt[(long)(cb * 32 + 4 * cg + 2 * j) * 9 + k], Wt[(long)(cb * 32 + 4 * cg + 2 * j + 1) * 9 + k]};
+  const int y1 = min(y0 + band, H);
+  // accumulators of output rows r-1 (a0), r (a1), r+1 (a2) while input row r is being scattered
+  f32x2 a0[SW][2], a1[SW][2], a2[SW][2];
+#pragma unroll
+  for (int s = 0; s < SW; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a0[s][j] = a1[s][j] = a2[s][j] = (f32x2){0.f, 0.f};
+  constexpr int D = 3;                 // input rows in flight ahead of the one being scattered
+  Raw3 q[D + 1][SW];
+#pragma unroll
+  for (int d = 0; d <= D; ++d)
+#pragma unroll
+    for (int s = 0; s < SW; ++s) q[d][s] = load_raw3(xp, y0 - 1 + d, x0 + 8 * s, H, W, cg);
+  // the ring is indexed statically (the row loop is unrolled D+1 times): a register that a load is still filling is never copied
+  for (int rb = y0 - 1; rb <= y1; rb += D + 1) {
+#pragma unroll
+    for (int u = 0; u <= D; ++u) {
+      const int r = rb + u;
+      if (r > y1) break;
+#pragma unroll
+      for (int s = 0; s < SW; ++s) {
+        const Raw3 cur = mask_raw3(q[u][s], r, x0 + 8 * s, H, W);
+        q[u][s] = load_raw3(xp, r + D + 1, x0 + 8 * s, H, W, cg);    // (rows past the band are loaded clamped and never used)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 l = up(cur.l[j]), c = up(cur.c[j]), rr = up(cur.r[j]);
+          // input row r is tap row ky = 2 of output r-1, ky = 1 of output r, ky = 0 of output r+1
+          a0[s][j] += l * w[6][j] + c * w[7][j] + rr * w[8][j];
+          a1[s][j] += l * w[3][j] + c * w[4][j] + rr * w[5][j];
+          a2[s][j] += l * w[0][j] + c * w[1][j] + rr * w[2][j];
+        }
+        if (r - 1 >= y0) {
+          u32x2 o = {pack2(a0[s][0][0], a0[s][0][1]), pack2(a0[s][1][0], a0[s][1][1])};
+          *reinterpret_cast<u32x2*>(yp + ((long)(r - 1) * W + x0 + 8 * s) * 32 + 4 * cg) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { a0[s][j] = a1[s][j]; a1[s][j] = a2[s][j]; a2[s][j] = (f32x2){0.f, 0.f}; }
+      }
+    }
+  }
+}
+
 int main() {
   const int H = 256, Wd = 256, Z = 32;
   const int band = getenv("BAND") ? atoi(getenv("BAND")) : 32;
@@ -124,8 +211,13 @@ int main() {
     dim3 grid((units + MW - 1) / MW, C / 32, Z);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const bool copy = getenv("COPY") != nullptr;
+    const int v2 = getenv("V2") ? atoi(getenv("V2")) : 0;     // strips of 8 pixels per wave
+    dim3 grid2(((Wd / (8 * std::max(v2, 1))) * ((H + band - 1) / band) + MW - 1) / MW, C / 32, Z);
     auto launch = [&]() {
-      if (copy) hipLaunchKernelGGL((dw_blocked_kernel<MW, 1>), grid, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
+      if (v2 == 1) hipLaunchKernelGGL((dw_blocked4_kernel<MW, 1>), grid2, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
+      else if (v2 == 2) hipLaunchKernelGGL((dw_blocked4_kernel<MW, 2>), grid2, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
+      else if (v2 == 4) hipLaunchKernelGGL((dw_blocked4_kernel<MW, 4>), grid2, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
+      else if (copy) hipLaunchKernelGGL((dw_blocked_kernel<MW, 1>), grid, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
       else hipLaunchKernelGGL((dw_blocked_kernel<MW, 0>), grid, dim3(64 * MW), 0, 0, X, Wt, Y, C, H, Wd, band);
     };
     for (int i = 0; i < 2; ++i) launch();
@@ -148,7 +240,7 @@ int main() {
       const double got = bf2f(hy[((size_t)(c / 32) * H * Wd + (size_t)y * Wd + x) * 32 + (c & 31)]);
       maxerr = fmax(maxerr, fabs(got - ref) / fmax(1.0, fabs(ref)));
     }
-    printf("blocked dw3x3 C=%4d %dx%d x%d band %d: %8.1f us  %6.0f GB/s   max rel err %.3g\n", C, H, Wd, Z, band, us, gb / us * 1e6, maxerr);
+    printf("blocked dw3x3 v2=%d C=%4d %dx%d x%d band %d: %8.1f us  %6.0f GB/s   max rel err %.3g\n", v2, C, H, Wd, Z, band, us, gb / us * 1e6, maxerr);
     CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(Wt));
   }
   return 0;
