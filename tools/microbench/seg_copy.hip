@@ -38,7 +38,7 @@ template <int SEG16> float run(const u32x4* in, u32x4* out, int B, int C, long N
   return ms / it;
 }
 int main() {
-  const int B = 8; const long N = 65536;
+  const int B = getenv("B") ? atoi(getenv("B")) : 8; const long N = 65536;
   for (int C : {48, 144, 254}) {
     size_t bytes = (size_t)B * C * N * 2;
     u32x4 *in, *out; CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes)); CK(hipMemset(in, 1, bytes));
