@@ -85,7 +85,7 @@ def pmc_traffic(kernel: str):
     with open(path) as f:
         table = json.load(f)
     import re
-    pat = re.compile(rf"{re.escape(kernel)}(_res|_dma|_stream|_wave)?_kernel")   # every variant booked under this profiler key
+    pat = re.compile(rf"{re.escape(kernel)}(_res|_dma|_stream|_wave|_wave_xres|_wave_stream)?_kernel")   # every variant booked under this profiler key
     tot = n = 0.0
     for name, row in table.items():
         if pat.search(name):

@@ -540,7 +540,302 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwG q) {
   pw_epilogue<T, MF>(p, reinterpret_cast<float*>(lds_dyn), acc, zb, zg, m0, n0, mw, lane, wv);
 }
 
-struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group, chunk_elems; int64_t slice_elems; size_t bytes; };
+// ---- wave-owned forms (bf16, 64-pixel-aligned rows) ---------------------------------------------------------------------------
+// The kernels above share every X chunk between the four waves of a workgroup, so a tile is a chain of workgroup barriers.  A
+// prototype on a channel-blocked layout (tools/microbench/pw_blocked.hip, profiles/r01_zz_pw_blocked_layout.txt) showed what
+// that costs: with the weights resident in LDS and every wave streaming its OWN pixel tiles - nothing a wave waits for except
+// its own loads - the same GEMMs ran at 5.0-5.6 TB/s instead of 3.8.  Most of that survives on plane-major NCHW
+// (tools/microbench/pw_plane.hip): the two transposes the layout forces (X chunk [k][px] -> k-contiguous MFMA operands; accumulators
+// -> 128-byte channel rows) go through a 4.5 KB LDS patch that belongs to ONE wave, so they need no workgroup barrier either.
+//   xres   (K <= 96, M > 96):  the whole weight matrix sits in LDS; a wave turns its X tile into operand registers once and walks
+//                              the output channels 32 at a time - X is read once, Y written once.
+//   stream (M <= 96, K <= 512): accumulators for every output channel; X streams through the patch one 32-k chunk at a time behind
+//                              two chunks of register prefetch.
+constexpr int PWW_MW = 8;                       // waves per workgroup
+constexpr int PWW_XS = 72;                      // patch row stride (elements): 64 pixels + pad, conflict-free transposed reads
+constexpr int PWW_PATCH = PW_KC * PWW_XS;       // bf16 elements per wave: one X chunk, or the fp32 slab of one 16-channel fragment
+static_assert(PWW_PATCH * 2 >= 16 * (PW_TN + 4) * 4, "the patch must hold a 16-row fp32 slab");
+
+struct PwwX {   // the X operand of slice z
+  const bf16* x1; const bf16* x2; int k1, ktot; int64_t n;
+};
+// raw global loads of one X chunk (32 k x 64 px): instruction i covers rows 8i + lane/8, 16 bytes (8 pixels) per lane
+__device__ __forceinline__ void pww_load_chunk(u32x4 (&raw)[4], const PwwX& x, int kb, int64_t n0, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = kb * PW_KC + 8 * i + (lane >> 3);
+    const int kc = k < x.ktot ? k : 0;          // rows past K read row 0 and are zeroed on the way into the patch
+    const bf16* row = kc < x.k1 ? x.x1 + (int64_t)kc * x.n : x.x2 + (int64_t)(kc - x.k1) * x.n;
+    raw[i] = *reinterpret_cast<const u32x4*>(row + n0 + 8 * (lane & 7));
+  }
+}
+// chunk -> patch -> MFMA A operands (same k-slot order as pw_chunk_mma: element j<4 of lane group g is k = 4g+j, j>=4 is 16+4g+j-4)
+__device__ __forceinline__ void pww_chunk_to_frags(s16x8 (&a)[4], const u32x4 (&raw)[4], bf16* patch, int kb, int ktot, int lane) {
+  const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * i + (lane >> 3);
+    *reinterpret_cast<u32x4*>(&patch[r * PWW_XS + 8 * (lane & 7)]) = kb * PW_KC + r < ktot ? raw[i] : zero4;
+  }
+  wave_lds_sync();
+  s16x4 lo[4], hi[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    lo[nf] = lds_tr_b16(&patch[(4 * g + qq) * PWW_XS + 16 * nf + 4 * pp]);
+    hi[nf] = lds_tr_b16(&patch[(16 + 4 * g + qq) * PWW_XS + 16 * nf + 4 * pp]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+               :
+               : "memory");
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) a[nf] = __builtin_shufflevector(lo[nf], hi[nf], 0, 1, 2, 3, 4, 5, 6, 7);
+  wave_lds_sync();
+}
+// B operand: 16 output channels; wr already points at this lane's row (li) and k offset (4g)
+__device__ __forceinline__ s16x8 pww_w_frag(const bf16* wr) {
+  const s16x4 lo = *reinterpret_cast<const s16x4*>(wr), hi = *reinterpret_cast<const s16x4*>(wr + 16);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// packed weight image of this workgroup's slice -> LDS, chunk images back to back ([tile][chunk][tm][WS_ROW])
+__device__ __forceinline__ void pww_stage_weights(bf16* Wl, const bf16* wpk, int images, int tm, int chunk_stride_elems, int t) {
+  const int vpc = tm * PwRow<bf16>::WS_ROW / 8;
+  for (int v = t; v < images * vpc; v += 64 * PWW_MW) {
+    const int c = v / vpc, o = v - c * vpc;
+    reinterpret_cast<u32x4*>(Wl)[v] = reinterpret_cast<const u32x4*>(wpk + (int64_t)c * chunk_stride_elems)[o];
+  }
+}
+struct PwwOut { bf16* y; const bf16* r; const float* bias; int m; int64_t n; };
+__device__ __forceinline__ void pww_load_res(u32x4 (&rr)[2], const PwwOut& o, int mbase, int64_t n0, int lane) {
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int m = mbase + it * 8 + (lane >> 3);
+    rr[it] = (o.r && m < o.m) ? *reinterpret_cast<const u32x4*>(o.r + (int64_t)m * o.n + n0 + 8 * (lane & 7)) : zero4;
+  }
+}
+// one 16-channel accumulator fragment (four pixel fragments) -> fp32 slab in the wave's patch -> + bias + residual -> 128-byte rows
+__device__ __forceinline__ void pww_store_frag(const f32x4 (&acc)[4], const u32x4 (&rr)[2], float* slab, const PwwOut& o, int mbase,
+                                               int64_t n0, int lane) {
+  constexpr int OS = PW_TN + 4;
+  const int li = lane & 15, g = lane >> 4, e_row = lane >> 3, e_col = (lane & 7) * 8;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    float v[4] = {acc[nf][0], acc[nf][1], acc[nf][2], acc[nf][3]};
+    Vec<float, 4>::st(&slab[li * OS + 16 * nf + 4 * g], v);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 8 + e_row, m = mbase + row;
+    if (m < o.m) {
+      float v[8];
+      Vec<float, 4>::ld(&slab[row * OS + e_col], v);
+      Vec<float, 4>::ld(&slab[row * OS + e_col + 4], v + 4);
+      const float bv = o.bias ? o.bias[m] : 0.f;
+      const u32x4 rv = rr[it];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[2 * j] += bv + bf16_bits_to_f32(rv[j] & 0xffffu);
+        v[2 * j + 1] += bv + bf16_bits_to_f32(rv[j] >> 16);
+      }
+      Vec<bf16, 8>::st(o.y + (int64_t)m * o.n + n0 + e_col, v);
+    }
+  }
+  wave_lds_sync();
+}
+
+// the same without a residual: bias is added in registers, the fragments are rounded once to bf16 and two of them (32 channels)
+// share one trip through the patch - half the LDS bytes and half the trips of the fp32 slab
+template <int NFR>
+__device__ __forceinline__ void pww_store_bf16(const f32x4 (&acc0)[4], const f32x4 (&acc1)[4], bf16* patch, const PwwOut& o, int mbase,
+                                               int64_t n0, int lane) {
+  const int li = lane & 15, g = lane >> 4, e_row = lane >> 3, e_col = (lane & 7) * 8;
+  const float b0 = (o.bias && mbase + li < o.m) ? o.bias[mbase + li] : 0.f;
+  const float b1 = (NFR > 1 && o.bias && mbase + 16 + li < o.m) ? o.bias[mbase + 16 + li] : 0.f;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    float v[4] = {acc0[nf][0] + b0, acc0[nf][1] + b0, acc0[nf][2] + b0, acc0[nf][3] + b0};
+    Vec<bf16, 4>::st(&patch[li * PWW_XS + 16 * nf + 4 * g], v);
+    if (NFR > 1) {
+      float u[4] = {acc1[nf][0] + b1, acc1[nf][1] + b1, acc1[nf][2] + b1, acc1[nf][3] + b1};
+      Vec<bf16, 4>::st(&patch[(16 + li) * PWW_XS + 16 * nf + 4 * g], u);
+    }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int it = 0; it < 2 * NFR; ++it) {
+    const int row = it * 8 + e_row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(&patch[row * PWW_XS + e_col]);
+    if (mbase + row < o.m) *reinterpret_cast<u32x4*>(o.y + (int64_t)(mbase + row) * o.n + n0 + e_col) = v;
+  }
+  wave_lds_sync();
+}
+
+template <int KB>
+__global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, int m_tiles, int tiles_per_wave, int chunk_stride_elems) {
+  const PwK& p = q.k;
+  constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  bf16* const Wl = reinterpret_cast<bf16*>(lds_dyn);                 // [m_tiles][KB][64][WS_ROW]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4;
+  bf16* const patch = Wl + (int64_t)m_tiles * KB * TM * WS_ROW + wv * PWW_PATCH;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, m_tiles * KB, TM,
+                    chunk_stride_elems, t);
+  __syncthreads();                                                   // the only workgroup barrier
+  PwwX x;
+  x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  x.x2 = p.x2 ? (const bf16*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : x.x1;
+  x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
+  PwwOut o;
+  o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
+  o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
+  o.m = p.m; o.n = p.n;
+  const int64_t n_tiles = p.n / PW_TN;
+  const int64_t tile0 = ((int64_t)blockIdx.x * PWW_MW + wv) * tiles_per_wave;
+  u32x4 raw[KB][4];
+  if (tile0 < n_tiles) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) pww_load_chunk(raw[kb], x, kb, tile0 * PW_TN, lane);
+  }
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int64_t tile = tile0 + tt;
+    if (tile >= n_tiles) break;
+    const int64_t n0 = tile * PW_TN;
+    s16x8 a[KB][4];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) pww_chunk_to_frags(a[kb], raw[kb], patch, kb, x.ktot, lane);
+    if (tt + 1 < tiles_per_wave && tile + 1 < n_tiles) {             // the next tile's X flies while this tile's channels are computed
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) pww_load_chunk(raw[kb], x, kb, n0 + PW_TN, lane);
+    }
+    for (int mh = 0; mh < 2 * m_tiles; ++mh) {                       // 32 output channels per trip
+      const int mbase = 32 * mh;
+      if (mbase >= p.m) break;
+      const bf16* wt = Wl + (int64_t)(mh >> 1) * KB * TM * WS_ROW + ((mh & 1) * 32 + li) * WS_ROW + 4 * g;
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const s16x8 b = pww_w_frag(wt + (kb * TM + 16 * f) * WS_ROW);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][nf], b, acc[f][nf], 0, 0, 0);
+        }
+      if (!o.r) {
+        pww_store_bf16<2>(acc[0], acc[1], patch, o, mbase, n0, lane);
+      } else {                                                       // (no model shape takes this branch: wide outputs carry no residual)
+        u32x4 rr[2];
+        pww_load_res(rr, o, mbase, n0, lane);
+        pww_store_frag(acc[0], rr, reinterpret_cast<float*>(patch), o, mbase, n0, lane);
+        pww_load_res(rr, o, mbase + 16, n0, lane);
+        pww_store_frag(acc[1], rr, reinterpret_cast<float*>(patch), o, mbase + 16, n0, lane);
+      }
+    }
+  }
+}
+
+template <int MF>
+__global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q, int tiles_per_wave, int chunk_stride_elems) {
+  const PwK& p = q.k;
+  constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 16 * MF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  bf16* const Wl = reinterpret_cast<bf16*>(lds_dyn);                 // [k_chunks][TM][WS_ROW]
+  const int nchunks = q.k_chunks;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4;
+  bf16* const patch = Wl + (int64_t)nchunks * TM * WS_ROW + wv * PWW_PATCH;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, nchunks, TM,
+                    chunk_stride_elems, t);
+  __syncthreads();
+  PwwX x;
+  x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  x.x2 = p.x2 ? (const bf16*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : x.x1;
+  x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
+  PwwOut o;
+  o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
+  o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
+  o.m = p.m; o.n = p.n;
+  const int64_t n_tiles = p.n / PW_TN;
+  const int64_t tile0 = ((int64_t)blockIdx.x * PWW_MW + wv) * tiles_per_wave;
+  const bf16* wl = Wl + li * WS_ROW + 4 * g;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int64_t tile = tile0 + tt;
+    if (tile >= n_tiles) break;
+    const int64_t n0 = tile * PW_TN;
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 r0[4], r1[4];                                              // two chunks in flight, statically named
+    pww_load_chunk(r0, x, 0, n0, lane);
+    if (nchunks > 1) pww_load_chunk(r1, x, 1, n0, lane);
+    for (int kb = 0; kb < nchunks; kb += 2) {
+      {
+        s16x8 a[4];
+        pww_chunk_to_frags(a, r0, patch, kb, x.ktot, lane);
+        if (kb + 2 < nchunks) pww_load_chunk(r0, x, kb + 2, n0, lane);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const s16x8 b = pww_w_frag(wl + (kb * TM + 16 * mf) * WS_ROW);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b, acc[mf][nf], 0, 0, 0);
+        }
+      }
+      if (kb + 1 < nchunks) {
+        s16x8 a[4];
+        pww_chunk_to_frags(a, r1, patch, kb + 1, x.ktot, lane);
+        if (kb + 3 < nchunks) pww_load_chunk(r1, x, kb + 3, n0, lane);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const s16x8 b = pww_w_frag(wl + ((kb + 1) * TM + 16 * mf) * WS_ROW);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b, acc[mf][nf], 0, 0, 0);
+        }
+      }
+    }
+    if (!o.r) {
+#pragma unroll
+      for (int mj = 0; mj < MF / 2; ++mj)
+        if (32 * mj < p.m) pww_store_bf16<2>(acc[2 * mj], acc[2 * mj + 1], patch, o, 32 * mj, n0, lane);
+      if (MF & 1)
+        if (16 * (MF - 1) < p.m) pww_store_bf16<1>(acc[MF - 1], acc[MF - 1], patch, o, 16 * (MF - 1), n0, lane);
+    } else {
+      u32x4 rr[2], rn[2];                                            // residual rows: one fragment ahead
+      pww_load_res(rr, o, 0, n0, lane);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        if (16 * mf >= p.m) break;
+        if (mf + 1 < MF) pww_load_res(rn, o, 16 * (mf + 1), n0, lane);
+        pww_store_frag(acc[mf], rr, reinterpret_cast<float*>(patch), o, 16 * mf, n0, lane);
+        rr[0] = rn[0]; rr[1] = rn[1];
+      }
+    }
+  }
+}
+
+struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group, chunk_elems, wave; int64_t slice_elems; size_t bytes; };
+constexpr size_t PWW_LDS_MAX = 160 * 1024;
+
+static bool pw_vec_ok(const mi_pw_desc* d) {
+  const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
+  bool ok = (d->n % vec == 0) && aligned16(d->x1) && aligned16(d->x2) && aligned16(d->y) && aligned16(d->r);
+  ok = ok && d->x1_bs % vec == 0 && d->x1_gs % vec == 0 && d->x2_bs % vec == 0 && d->x2_gs % vec == 0;
+  ok = ok && d->y_bs % vec == 0 && d->y_gs % vec == 0 && d->r_bs % vec == 0 && d->r_gs % vec == 0;
+  return ok;
+}
+
 
 static PwPlan pw_plan(const mi_pw_desc* d) {
   PwPlan pl;
@@ -564,8 +859,23 @@ static PwPlan pw_plan(const mi_pw_desc* d) {
       if (!pl.tm || cost < best_cost) { pl.tm = tm; best_cost = cost; }
     }
   }
-  pl.m_tiles = cdiv(d->m, pl.tm);
   pl.k_chunks = cdiv(d->k1 + d->k2, PW_KC);
+  // wave-owned forms (1: xres, 2: stream) where their LDS budget holds; they fix the packed tile height
+  pl.wave = 0;
+  {
+    const char* e = getenv("MI_PW_WAVE");
+    const bool off = (e && e[0] == '0') || getenv("MI_PW_DMA") || getenv("MI_PW_CHUNKED");
+    if (!off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
+      const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
+      if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches <= PWW_LDS_MAX) {
+        pl.wave = 1; pl.tm = 64;
+      } else if (d->m <= 96 && pl.k_chunks <= 16) {
+        const int tm = d->m > 64 ? 96 : d->m > 48 ? 64 : 48;
+        if ((size_t)pl.k_chunks * tm * row + patches <= PWW_LDS_MAX) { pl.wave = 2; pl.tm = tm; }
+      }
+    }
+  }
+  pl.m_tiles = cdiv(d->m, pl.tm);
   pl.per_batch = d->w_bs != 0;
   pl.per_group = d->w_gs != 0;
   pl.slices = (pl.per_batch ? d->batch : 1) * (pl.per_group ? d->groups : 1);
@@ -660,7 +970,38 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   // per-tile prologue and epilogue dominate and its 3 x chunk LDS footprint halves the resident workgroups).  It stays
   // opt-in (MI_PW_DMA=1) as the base of a persistent cross-tile pipeline; tests run it through the same parity cases.
   const bool dma = getenv("MI_PW_DMA") != nullptr;
-  if (k.vec_ok && dma) {
+  if (pl.wave) {
+    if constexpr (std::is_same<T, bf16>::value) {
+      const int64_t n_tiles = k.n / PW_TN;
+      const size_t row = PwRow<bf16>::WS_ROW * sizeof(bf16), patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16);
+      const size_t wbytes = (size_t)pl.m_tiles * pl.k_chunks * pl.tm * row;
+      // pixel tiles per wave: 2, or 4 to amortise a weight image near the LDS limit (510 x 96 at 256^2, bs 32: 535 vs 565 us;
+      // the smaller images lose 2-3% at 4), while at least ~4 workgroups per CU remain
+      int64_t tpw = wbytes > 96 * 1024 ? 4 : 2;
+      const int64_t par = n_tiles * grid.z / ((int64_t)PWW_MW * 256 * 4);
+      if (tpw > par) tpw = par;
+      if (const char* e = getenv("MI_PW_WAVE_TPW")) tpw = atoi(e);
+      if (tpw < 1) tpw = 1;
+      if (tpw > 8) tpw = 8;
+      dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), 1, grid.z), wblock(64 * PWW_MW);
+      const size_t lds = wbytes + patches;
+#define PWW_LAUNCH(KERNEL, ...)                                                                                              \
+  do {                                                                                                                       \
+    if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(KERNEL, wgrid, wblock, lds, st, q, __VA_ARGS__);                                                      \
+  } while (0)
+      if (pl.wave == 1) {
+        if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else if (pl.k_chunks == 2) PWW_LAUNCH((pw_gemm_wave_xres_kernel<2>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_xres_kernel<3>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+      } else {
+        if (pl.tm == 96) PWW_LAUNCH((pw_gemm_wave_stream_kernel<6>), (int)tpw, pl.chunk_elems);
+        else if (pl.tm == 64) PWW_LAUNCH((pw_gemm_wave_stream_kernel<4>), (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_stream_kernel<3>), (int)tpw, pl.chunk_elems);
+      }
+#undef PWW_LAUNCH
+    }
+  } else if (k.vec_ok && dma) {
     if (pl.tm == 128) MI_TRY((pw_launch_dma<T, 2>(q, grid, st)));
     else MI_TRY((pw_launch_dma<T, 1>(q, grid, st)));
   } else if (std::is_same<T, bf16>::value && k.vec_ok && pl.k_chunks <= PWR_MAXC && k.m > 64 && !getenv("MI_PW_CHUNKED")) {
@@ -719,7 +1060,6 @@ extern "C" size_t mi_pw_gemm_workspace(const mi_pw_desc* d) {
 extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   MI_TRY(pw_check(d));
   MI_CHECK_ARG(ws && aligned16(ws), "pw_gemm: workspace missing or not 16-byte aligned");
-  const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
   PwK k;
   k.x1 = d->x1; k.x1_bs = d->x1_bs; k.x1_gs = d->x1_gs; k.k1 = d->k1;
   k.x2 = d->x2; k.x2_bs = d->x2_bs; k.x2_gs = d->x2_gs; k.k2 = d->k2;
@@ -728,9 +1068,7 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   k.r = d->r; k.r_bs = d->r_bs; k.r_gs = d->r_gs;
   k.y = d->y; k.y_bs = d->y_bs; k.y_gs = d->y_gs;
   k.m = d->m; k.n = d->n; k.groups = d->groups;
-  bool ok = (d->n % vec == 0) && aligned16(d->x1) && aligned16(d->x2) && aligned16(d->y) && aligned16(d->r);
-  ok = ok && d->x1_bs % vec == 0 && d->x1_gs % vec == 0 && d->x2_bs % vec == 0 && d->x2_gs % vec == 0;
-  ok = ok && d->y_bs % vec == 0 && d->y_gs % vec == 0 && d->r_bs % vec == 0 && d->r_gs % vec == 0;
+  const bool ok = pw_vec_ok(d);
   k.vec_ok = ok ? 1 : 0;
   const PwPlan pl = pw_plan(d);
   hipStream_t st = (hipStream_t)stream;

@@ -280,7 +280,7 @@ def test_block_at_training_resolution_vs_oracle(dtype, tol, c, heads, hw):
 
 
 @pytest.mark.parametrize("env", ["MI_GRAM_LDS", "MI_GRAM_STREAM_ALL", "MI_PW_CHUNKED", "MI_PW_TM_EVEN", "MI_DW_LDS",
-                                 "MI_GDFN_STORE_Y", "MI_LN_FORM=block", "MI_LN_FORM=wave", "MI_PW_DMA"])
+                                 "MI_GDFN_STORE_Y", "MI_LN_FORM=block", "MI_LN_FORM=wave", "MI_PW_DMA", "MI_PW_WAVE=0"])
 def test_alternate_kernel_paths_stay_correct(monkeypatch, env):
     """Every A/B switch selects a kernel that is otherwise only reached for other shapes (or not at all): run one block
     at a training-size plane through each and hold it to the same bound as the default path."""

@@ -303,3 +303,31 @@ def test_pw_full_descriptor_exact_on_integers(monkeypatch, dma, dtype, transpose
     y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), bias.to(DEV), res.to(DEV), M, groups,
                 per_image, transposed)
     assert torch.equal(y.float().cpu(), ref), f"max diff {(y.float().cpu() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("epilogue", ["none", "bias"])
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("M,K,groups,per_image", [(510, 96, 1, False), (254, 48, 1, False), (144, 40, 1, False), (96, 510, 1, False),
+                                                  (48, 127, 1, False), (70, 200, 1, False), (96, 96, 1, True), (48, 48, 2, True),
+                                                  (130, 33, 1, False)])
+def test_pw_wave_forms_without_residual(monkeypatch, epilogue, transposed, M, K, groups, per_image):
+    """The wave-owned GEMM forms (64-pixel-aligned bf16 rows) store through a bf16 patch when there is no residual: wide outputs
+    (all channels walked 32 at a time), narrow outputs over long K, odd K tails, M tails inside a 32-channel pair, bias alone.
+    Integer data -> exact; the chunked kernel (MI_PW_WAVE=0) must give the same bits."""
+    B, hw = 2, (16, 64)
+    dtype = torch.bfloat16
+    x1 = ints((B, groups * K, *hw), 191).to(dtype)
+    w = ints((B if per_image else 1, groups, M, K), 193, -2, 3)
+    bias = ints((groups, M), 194) if epilogue == "bias" else None
+    ref = torch.einsum("bgmk,bgkn->bgmn", w.expand(B, -1, -1, -1), x1.float().reshape(B, groups, K, -1))
+    if bias is not None:
+        ref = ref + bias[None, :, :, None]
+    ref = ref.reshape(B, groups * M, *hw).to(dtype).float()
+    warg = w.transpose(-1, -2).contiguous() if transposed else w
+    outs = []
+    for wave in ("1", "0"):
+        monkeypatch.setenv("MI_PW_WAVE", wave)
+        y = _pw_raw(x1.to(DEV), None, warg.to(DEV), None if bias is None else bias.to(DEV), None, M, groups, per_image, transposed)
+        outs.append(y.float().cpu())
+    assert torch.equal(outs[0], ref), f"max diff {(outs[0] - ref).abs().max()}"
+    assert torch.equal(outs[1], ref)
