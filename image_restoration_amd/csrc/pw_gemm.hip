@@ -754,8 +754,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   bf16* const patch = Wl + (int64_t)nchunks * TM * WS_ROW + wv * PWW_PATCH;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
-  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, nchunks, TM,
-                    chunk_stride_elems, t);
+  const int m0 = blockIdx.y * TM;                                    // wide outputs: one workgroup per 16 MF-channel tile (X is re-read per tile)
+  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
+                            (int64_t)blockIdx.y * nchunks * chunk_stride_elems, nchunks, TM, chunk_stride_elems, t);
   __syncthreads();
   PwwX x;
   x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
@@ -808,17 +809,17 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
     if (!o.r) {
 #pragma unroll
       for (int mj = 0; mj < MF / 2; ++mj)
-        if (32 * mj < p.m) pww_store_bf16<2>(acc[2 * mj], acc[2 * mj + 1], patch, o, 32 * mj, n0, lane);
+        if (m0 + 32 * mj < p.m) pww_store_bf16<2>(acc[2 * mj], acc[2 * mj + 1], patch, o, m0 + 32 * mj, n0, lane);
       if (MF & 1)
-        if (16 * (MF - 1) < p.m) pww_store_bf16<1>(acc[MF - 1], acc[MF - 1], patch, o, 16 * (MF - 1), n0, lane);
+        if (m0 + 16 * (MF - 1) < p.m) pww_store_bf16<1>(acc[MF - 1], acc[MF - 1], patch, o, m0 + 16 * (MF - 1), n0, lane);
     } else {
       u32x4 rr[2], rn[2];                                            // residual rows: one fragment ahead
-      pww_load_res(rr, o, 0, n0, lane);
+      pww_load_res(rr, o, m0, n0, lane);
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        if (16 * mf >= p.m) break;
-        if (mf + 1 < MF) pww_load_res(rn, o, 16 * (mf + 1), n0, lane);
-        pww_store_frag(acc[mf], rr, reinterpret_cast<float*>(patch), o, 16 * mf, n0, lane);
+        if (m0 + 16 * mf >= p.m) break;
+        if (mf + 1 < MF) pww_load_res(rn, o, m0 + 16 * (mf + 1), n0, lane);
+        pww_store_frag(acc[mf], rr, reinterpret_cast<float*>(patch), o, m0 + 16 * mf, n0, lane);
         rr[0] = rn[0]; rr[1] = rn[1];
       }
     }
@@ -869,9 +870,20 @@ static PwPlan pw_plan(const mi_pw_desc* d) {
       const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
-      } else if (d->m <= 96 && pl.k_chunks <= 16) {
-        const int tm = d->m > 64 ? 96 : d->m > 48 ? 64 : 48;
-        if ((size_t)pl.k_chunks * tm * row + patches <= PWW_LDS_MAX) { pl.wave = 2; pl.tm = tm; }
+      } else {
+        // stream: one 96- / 64- / 48-channel tile per workgroup; wide outputs tile M (every tile streams X again, like the
+        // chunked kernel), preferring the tile height that moves the fewest rows and fits beside the patches
+        int best = 0;
+        int64_t best_cost = 0;
+        for (int tm : {96, 64, 48}) {
+          if (d->m <= 48 && tm != 48) continue;
+          if (d->m <= 64 && tm == 96) continue;
+          if ((size_t)pl.k_chunks * tm * row + patches > PWW_LDS_MAX) continue;
+          const int64_t cost = (int64_t)cdiv(d->m, tm) * (d->k1 + d->k2 + tm);
+          if (!best || cost < best_cost) { best = tm; best_cost = cost; }
+        }
+        const char* w = getenv("MI_PW_WAVE_WIDE");
+        if (best && (d->m <= 96 || !(w && w[0] == '0'))) { pl.wave = 2; pl.tm = best; }
       }
     }
   }
@@ -974,16 +986,16 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     if constexpr (std::is_same<T, bf16>::value) {
       const int64_t n_tiles = k.n / PW_TN;
       const size_t row = PwRow<bf16>::WS_ROW * sizeof(bf16), patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16);
-      const size_t wbytes = (size_t)pl.m_tiles * pl.k_chunks * pl.tm * row;
+      const size_t wbytes = (size_t)(pl.wave == 1 ? pl.m_tiles : 1) * pl.k_chunks * pl.tm * row;
       // pixel tiles per wave: 2, or 4 to amortise a weight image near the LDS limit (510 x 96 at 256^2, bs 32: 535 vs 565 us;
       // the smaller images lose 2-3% at 4), while at least ~4 workgroups per CU remain
       int64_t tpw = wbytes > 96 * 1024 ? 4 : 2;
-      const int64_t par = n_tiles * grid.z / ((int64_t)PWW_MW * 256 * 4);
+      const int64_t par = n_tiles * grid.z * (pl.wave == 2 ? pl.m_tiles : 1) / ((int64_t)PWW_MW * 256 * 4);
       if (tpw > par) tpw = par;
       if (const char* e = getenv("MI_PW_WAVE_TPW")) tpw = atoi(e);
       if (tpw < 1) tpw = 1;
       if (tpw > 8) tpw = 8;
-      dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), 1, grid.z), wblock(64 * PWW_MW);
+      dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), pl.wave == 2 ? pl.m_tiles : 1, grid.z), wblock(64 * PWW_MW);
       const size_t lds = wbytes + patches;
 #define PWW_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                       \
