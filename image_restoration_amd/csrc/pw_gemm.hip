@@ -838,7 +838,7 @@ static bool pw_vec_ok(const mi_pw_desc* d) {
 }
 
 
-static PwPlan pw_plan(const mi_pw_desc* d) {
+static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
   PwPlan pl;
   // m-tile 128 when its padding stays within 25% of the 64-granular minimum, else 64.  (256-row tiles measured 5-8%
   // slower on the wide GDFN shapes: fewer resident workgroups; profiles/r01_n_pw_tile_staging_ab.log)
@@ -866,7 +866,7 @@ static PwPlan pw_plan(const mi_pw_desc* d) {
   {
     const char* e = getenv("MI_PW_WAVE");
     const bool off = (e && e[0] == '0') || getenv("MI_PW_DMA") || getenv("MI_PW_CHUNKED");
-    if (!off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
+    if (allow_wave && !off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
       const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
@@ -1066,7 +1066,10 @@ using namespace mi;
 
 extern "C" size_t mi_pw_gemm_workspace(const mi_pw_desc* d) {
   if (!d || d->m <= 0 || d->k1 <= 0 || d->k2 < 0 || d->batch <= 0 || d->groups <= 0) return 0;
-  return pw_plan(d).bytes;
+  // the wave-owned forms tile the packed image differently; which form runs depends on pointer alignment at call time, and module
+  // entry points size their workspaces before they see the pointers: cover both
+  const size_t a = pw_plan(d).bytes, b = pw_plan(d, false).bytes;
+  return a > b ? a : b;
 }
 
 extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
