@@ -8,6 +8,12 @@
 // 16-byte copy (measured: per-tile scalar fp32 staging cost more issue slots than everything else in the kernel).
 // The epilogue stages accumulators through LDS and writes whole 128-byte row segments, 16 bytes per lane.
 // bf16 activations use v_mfma_f32_16x16x32_bf16, fp32 activations the exact v_mfma_f32_16x16x4_f32.
+// Kernel families, in the order pw_launch tries them:
+//   pw_gemm_wave_xres / pw_gemm_wave_stream  bf16, rows of whole 64-pixel tiles: weights resident in LDS, every wave streams its own
+//                                            pixel tiles through a private transpose patch - no workgroup barriers (the default)
+//   pw_gemm_res                              bf16, K <= 128: weight-resident persistent workgroups sharing each X chunk (MI_PW_WAVE=0)
+//   pw_gemm                                  any dtype / alignment / ragged pixel counts: chunked through LDS (MI_PW_CHUNKED=1)
+//   pw_gemm_dma                              opt-in LDS-DMA ring (MI_PW_DMA=1)
 #include <stdlib.h>
 
 #include <algorithm>
