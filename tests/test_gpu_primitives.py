@@ -331,3 +331,45 @@ def test_pw_wave_forms_without_residual(monkeypatch, epilogue, transposed, M, K,
         outs.append(y.float().cpu())
     assert torch.equal(outs[0], ref), f"max diff {(outs[0] - ref).abs().max()}"
     assert torch.equal(outs[1], ref)
+
+
+def test_pw_wave_forms_fuzz_against_chunked(monkeypatch):
+    """Seeded sweep over the descriptor space the wave-owned forms accept (M 1..600, K 1..520 in one or two panels, head groups,
+    per-image weights, bias / residual on or off, odd tile counts): integer data, so the wave-owned kernels, the chunked kernel and the
+    host result must agree exactly."""
+    import random
+    rng = random.Random(20260101)
+    dtype = torch.bfloat16
+    for case in range(40):
+        M = rng.choice([1, 7, 16, 24, 48, 49, 64, 65, 96, 97, 127, 130, 192, 255, 300, 510, 600])
+        K = rng.choice([1, 5, 32, 33, 48, 64, 96, 97, 127, 160, 192, 255, 288, 384, 510, 520])
+        two = rng.random() < 0.3 and K >= 2
+        K1 = rng.randint(1, K - 1) if two else K
+        K2 = K - K1
+        groups = rng.choice([1, 1, 1, 2, 3]) if M * K <= 130 * 130 else 1
+        per_image = rng.random() < 0.3
+        transposed = rng.random() < 0.5
+        hw = rng.choice([(8, 8), (1, 64), (3, 64), (8, 72), (16, 64)])        # 1, 1, 3, 9, 16 tiles of 64 pixels
+        use_bias, use_res = rng.random() < 0.5, rng.random() < 0.5
+        B = 2
+        x1 = ints((B, groups * K1, *hw), 1000 + case).to(dtype)
+        x2 = ints((B, groups * K2, *hw), 2000 + case).to(dtype) if K2 else None
+        w = ints((B if per_image else 1, groups, M, K), 3000 + case, -2, 3)
+        bias = ints((groups, M), 4000 + case) if use_bias else None
+        res = ints((B, groups * M, *hw), 5000 + case).to(dtype) if use_res else None
+        xs = x1.float().reshape(B, groups, K1, -1)
+        if K2:
+            xs = torch.cat([xs, x2.float().reshape(B, groups, K2, -1)], 2)
+        ref = torch.einsum("bgmk,bgkn->bgmn", w.expand(B, -1, -1, -1), xs)
+        if bias is not None:
+            ref = ref + bias[None, :, :, None]
+        ref = ref.reshape(B, groups * M, *hw)
+        if res is not None:
+            ref = ref + res.float()
+        ref = ref.to(dtype).float()
+        warg = w.transpose(-1, -2).contiguous() if transposed else w
+        for wave in ("1", "0"):
+            monkeypatch.setenv("MI_PW_WAVE", wave)
+            y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), None if bias is None else bias.to(DEV),
+                        None if res is None else res.to(DEV), M, groups, per_image, transposed)
+            assert torch.equal(y.float().cpu(), ref), (case, wave, M, K1, K2, groups, per_image, transposed, hw, use_bias, use_res)
