@@ -74,6 +74,11 @@ class GdfnParams(C.Structure):
     _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp)]
 
 
+class GdfnFusedShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("ln_with_bias", C.c_int)]
+
+
 class GdfnGrads(C.Structure):
     _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp),
                 ("accumulate", C.c_int)]
@@ -119,6 +124,10 @@ SIGNATURES = {
     "mi_gdfn_fwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, vp, vp, vp]),
     "mi_gdfn_bwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, C.POINTER(GdfnGrads), vp, vp,
                               vp]),
+    "mi_gdfn_fused_ok": (C.c_int, [C.POINTER(GdfnFusedShape)]),
+    "mi_gdfn_fused_pack_bytes": (C.c_size_t, [C.POINTER(GdfnFusedShape)]),
+    "mi_gdfn_fused_pack": (C.c_int, [C.POINTER(GdfnFusedShape), fp, fp, C.POINTER(GdfnParams), vp, vp]),
+    "mi_gdfn_fused_fwd": (C.c_int, [C.POINTER(GdfnFusedShape), vp, vp, vp, fp, fp, vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, fp, vp]),
     "mi_rows_gather": (C.c_int, [vp, vp, vp, C.c_int, c_i64, C.c_int, vp]),

@@ -1,0 +1,591 @@
+// Fused GDFN half-block, forward:  out = y + project_out( gelu(dw(project_in(LN(y)))[0:h]) * dw(...)[h:2h] )
+// (Restormer.py:76-93 FeedForward + :148 `x + ffn(norm2(x))`; moce_ir.py:255-276,834; AdaIR-main/net/model.py:76-94,170)
+// in ONE launch: y is read once (plus a one-pixel halo), out is written once, nothing else touches HBM.
+//
+// Work decomposition (bf16 activations, fp32 accumulate):
+//   * a workgroup (8 waves) owns a TH x 64 pixel tile of one image and keeps, for the whole kernel,
+//       - LN(y) on the tile + halo as MFMA A-operand fragments in registers (wave w owns 16-pixel m-tiles w, w+8, ...),
+//       - the fp32 accumulators of the output tile (wave w owns tile rows w, w+8: 96 registers per lane).
+//   * the hidden dimension is walked in chunks of PC gate pairs (channels j and j+h ride together):
+//       GEMM1   h0[2PC][tile+halo] = W_in'[chunk] . LN(y)          MFMA 16x16x32/16x16x16, result -> LDS (bf16, zero outside
+//                                                                    the image = the depthwise conv's zero padding)
+//       conv    g[PC][tile] = gelu(dw3x3(h0[j])) * dw3x3(h0[j+h])  VALU, packed fp32 (the pair in the two halves), 8 pixels
+//                                                                    of a row per lane, neighbours by DPP, result -> LDS
+//       GEMM2   acc[tile][C] += g^T . W_out[chunk]^T               MFMA, A operand = transposed LDS reads of g
+//     with two workgroup barriers per chunk; the next chunk's weights are staged into LDS behind the conv phase.
+//   * LayerNorm's affine is folded into the packed weights (W_in' = W_in diag(gamma), b' = W_in beta + b_in), so the
+//     kernel only centres and scales; mean / rstd of the tile's own pixels are written for the backward pass.
+// Pixel index space of a tile ("linear halo pixel"): [0, HR*64) = rows y0-1 .. y0+TH of the 64 tile columns,
+// then HR left-halo pixels (column x0-1), then HR right-halo pixels (column x0+64), padded to a multiple of 16.
+#include <stdlib.h>
+
+#include "fused_common.h"
+#include "internal.h"
+
+namespace mi {
+using namespace fz;
+
+template <int C_, int TH_, int PC_> struct FgCfg {
+  static constexpr int C = C_, TH = TH_, PC = PC_;
+  static constexpr int HR = TH + 2;
+  static constexpr int BODY = HR * 64;
+  static constexpr int HPX = BODY + 2 * HR;
+  static constexpr int HPXP = (HPX + 15) / 16 * 16;
+  static constexpr int MT = HPXP / 16;                 // 16-pixel m-tiles of GEMM1
+  static constexpr int MTW = (MT + 7) / 8;             // per wave
+  static constexpr int PLANE = (HPXP % 16 == 8) ? HPXP : HPXP + 8;   // plane stride (elements): 16-byte aligned planes
+  static constexpr int KS32 = C / 32, KT16 = (C % 32) / 16;
+  static constexpr int NV = 8 * KS32 + 4 * KT16;       // channel values per lane per pixel (C / 4)
+  static constexpr int W1S = C + 8;                    // LDS row strides (elements): conflict-free 8-byte operand reads
+  static constexpr int W2S = PC + 8;
+  static constexpr int GS = TH * 64 + 16;              // g row stride: conflict-free transposed reads
+  static constexpr int NT1 = 2 * PC / 16;              // 16-channel n-tiles of GEMM1
+  static constexpr int CT = C / 16;                    // 16-channel tiles of the output
+  static constexpr int RP = TH / 8;                    // tile rows per wave (and conv row passes)
+  static constexpr int PPW = PC / 8;                   // gate pairs per wave per chunk
+  static constexpr int H0_BYTES = 2 * PC * PLANE * 2;
+  static constexpr int G_BYTES = PC * GS * 2;
+  static constexpr int W1_BYTES = 2 * PC * W1S * 2;
+  static constexpr int W2_BYTES = C * W2S * 2;
+  static constexpr int S_BYTES = C * PLANE * 2;        // prologue: raw y staged plane-major (aliases everything)
+  static constexpr int MAIN_BYTES = H0_BYTES + G_BYTES + W1_BYTES + W2_BYTES;
+  static constexpr int LDS_BYTES = MAIN_BYTES > S_BYTES ? MAIN_BYTES : S_BYTES;
+  static constexpr int SLAB_OS = 68;                   // epilogue: wave-private fp32 slab [16 ch][64 px + pad]
+  static_assert(C % 16 == 0 && TH % 8 == 0 && PC % 8 == 0 && (PC == 16 || PC == 32), "unsupported tile");
+  static_assert(8 * 16 * SLAB_OS * 4 <= H0_BYTES, "epilogue slabs live in the h0 region");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+struct FgArgs {
+  const bf16* y; bf16* out; float* mean; float* rstd;
+  const bf16* w1p; const bf16* w2p; const float* b1p; const float* wdp; const float* b2;
+  int B, H, W, nch, with_bias, tiles_x, tiles_y, dbg;
+};
+
+// packed-weight blob layout (bytes from its base), shared by the pack kernel and the launcher
+struct FgPackLayout { size_t w1p, w2p, b1p, wdp, b2, bytes; int nch; };
+static FgPackLayout fg_pack_layout(int C, int hidden, int PC) {
+  FgPackLayout l;
+  l.nch = cdiv(hidden, PC);
+  size_t off = 0;
+  l.w1p = off; off = align_up(off + (size_t)l.nch * 2 * PC * (C + 8) * 2, 256);
+  l.w2p = off; off = align_up(off + (size_t)l.nch * C * (PC + 8) * 2, 256);
+  l.b1p = off; off = align_up(off + (size_t)l.nch * 2 * PC * 4, 256);
+  l.wdp = off; off = align_up(off + (size_t)l.nch * PC * 20 * 4, 256);
+  l.b2 = off; off = align_up(off + (size_t)C * 4, 256);
+  l.bytes = off;
+  return l;
+}
+
+struct FgPackArgs {
+  const float *ln_w, *ln_b, *in_w, *in_b, *dw_w, *dw_b, *out_w, *out_b;
+  bf16* w1p; bf16* w2p; float* b1p; float* wdp; float* b2;
+  int C, h, PC, nch;
+};
+
+__global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
+  const int C = a.C, h = a.h, PC = a.PC, W1S = C + 8, W2S = PC + 8;
+  const int64_t n_w1 = (int64_t)a.nch * 2 * PC * W1S, n_w2 = (int64_t)a.nch * C * W2S, n_b1 = (int64_t)a.nch * 2 * PC,
+                n_wd = (int64_t)a.nch * PC * 20, n_b2 = C;
+  const int64_t total = n_w1 + n_w2 + n_b1 + n_wd + n_b2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    int64_t r = e;
+    if (r < n_w1) {                                   // W_in'[chunk][row][k] = W_in[hidden row][k] * gamma[k]
+      const int k = (int)(r % W1S); r /= W1S;
+      const int rr = (int)(r % (2 * PC)), c = (int)(r / (2 * PC));
+      const int jl = c * PC + rr % PC, hid = (rr / PC) * h + jl;
+      const float v = (k < C && jl < h) ? a.in_w[(int64_t)hid * C + k] * a.ln_w[k] : 0.f;
+      a.w1p[e] = (bf16)v;
+      continue;
+    }
+    r -= n_w1;
+    if (r < n_w2) {                                   // W_out^T chunk: [chunk][out channel][pair]
+      const int kk = (int)(r % W2S); r /= W2S;
+      const int n = (int)(r % C), c = (int)(r / C);
+      const int jl = c * PC + kk;
+      a.w2p[r * W2S + kk] = (bf16)((kk < PC && jl < h) ? a.out_w[(int64_t)n * h + jl] : 0.f);
+      continue;
+    }
+    r -= n_w2;
+    if (r < n_b1) {                                   // b' = b_in + W_in . beta
+      const int rr = (int)(r % (2 * PC)), c = (int)(r / (2 * PC));
+      const int jl = c * PC + rr % PC, hid = (rr / PC) * h + jl;
+      float s = 0.f;
+      if (jl < h) {
+        s = a.in_b ? a.in_b[hid] : 0.f;
+        if (a.ln_b)
+          for (int k = 0; k < C; ++k) s += a.in_w[(int64_t)hid * C + k] * a.ln_b[k];
+      }
+      a.b1p[r] = s;
+      continue;
+    }
+    r -= n_b1;
+    if (r < n_wd) {                                   // [chunk][pair][tap 0..8, bias][half]
+      const int half = (int)(r % 2); int64_t q = r / 2;
+      const int tp = (int)(q % 10); q /= 10;
+      const int p = (int)(q % PC), c = (int)(q / PC);
+      const int jl = c * PC + p, hid = half * h + jl;
+      float v = 0.f;
+      if (jl < h) v = tp < 9 ? a.dw_w[(int64_t)hid * 9 + tp] : (a.dw_b ? a.dw_b[hid] : 0.f);
+      a.wdp[r] = v;
+      continue;
+    }
+    r -= n_wd;
+    a.b2[r] = a.out_b ? a.out_b[r] : 0.f;
+  }
+}
+
+template <int C, int TH, int PC>
+__global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
+  using K = FgCfg<C, TH, PC>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fg_lds[];
+  bf16* const H0 = reinterpret_cast<bf16*>(fg_lds);
+  bf16* const G = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES);
+  bf16* const W1 = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES + K::G_BYTES);
+  bf16* const W2 = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES + K::G_BYTES + K::W1_BYTES);
+  bf16* const S = reinterpret_cast<bf16*>(fg_lds);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int x0 = tx * 64, y0 = ty * TH;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const bf16* const yb = a.y + (int64_t)b * C * HW;
+
+  // ---------------------------------------------------------------- prologue: stage raw y (tile + halo), plane-major
+  {
+    constexpr int NB = C * K::HR * 8;                  // 16-byte vectors of the tile body
+    for (int idx = t; idx < NB; idx += 512) {
+      const int c = idx / (K::HR * 8), rem = idx - c * (K::HR * 8), r = rem >> 3, u = rem & 7;
+      const int Y = y0 - 1 + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (Y >= 0 && Y < a.H) v = *reinterpret_cast<const u32x4*>(yb + (int64_t)c * HW + (int64_t)Y * a.W + x0 + 8 * u);
+      *reinterpret_cast<u32x4*>(&S[c * K::PLANE + r * 64 + 8 * u]) = v;
+    }
+    constexpr int NE = K::HPXP - K::BODY;              // halo-column pixels + padding per plane
+    for (int idx = t; idx < C * NE; idx += 512) {
+      const int c = idx / NE, k = idx - c * NE;
+      u16 v = 0;
+      if (k < 2 * K::HR) {
+        const int side = k >= K::HR ? 1 : 0, r = k - side * K::HR;
+        const int Y = y0 - 1 + r, X = side ? x0 + 64 : x0 - 1;
+        if (Y >= 0 && Y < a.H && X >= 0 && X < a.W)
+          v = reinterpret_cast<const u16*>(yb)[(int64_t)c * HW + (int64_t)Y * a.W + X];
+      }
+      reinterpret_cast<u16*>(S)[c * K::PLANE + K::BODY + k] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- LN(y) -> A-operand fragments (registers)
+  // element order of a 32-k fragment (same for A and B): j < 4 is k = 4g + j, j >= 4 is k = 16 + 4g + (j - 4)
+  s16x8 xa[K::MTW][K::KS32 > 0 ? K::KS32 : 1];
+  s16x4 xt[K::MTW];
+  unsigned long long vmask = 0;                        // bit 4i + r: pixel r of this lane's row group in m-tile i is inside the image
+#pragma unroll
+  for (int i = 0; i < K::MTW; ++i) {
+    const int mt = wv + 8 * i;
+    if (mt < K::MT) {
+      const bf16* sp = &S[(4 * g + qq) * K::PLANE + mt * 16 + 4 * pp];
+      s16x4 lo[K::KS32 > 0 ? K::KS32 : 1], hi[K::KS32 > 0 ? K::KS32 : 1], tl = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < K::KS32; ++ks) {
+        lo[ks] = tr_b16(sp + (ks * 32) * K::PLANE);
+        hi[ks] = tr_b16(sp + (ks * 32 + 16) * K::PLANE);
+      }
+      if (K::KT16) tl = tr_b16(sp + (K::KS32 * 32) * K::PLANE);
+      if constexpr (K::KS32 == 3) lds_wait(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], tl, dm);
+      else if constexpr (K::KS32 == 2) lds_wait(lo[0], hi[0], lo[1], hi[1], tl, dm);
+      else if constexpr (K::KS32 == 1) lds_wait(lo[0], hi[0], tl, dm);
+      else lds_wait(tl);
+      float v[K::NV];
+#pragma unroll
+      for (int ks = 0; ks < K::KS32; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[8 * ks + j] = bf_s(lo[ks][j]); v[8 * ks + 4 + j] = bf_s(hi[ks][j]); }
+      if (K::KT16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[8 * K::KS32 + j] = bf_s(tl[j]);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < K::NV; ++j) s += v[j];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mu = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < K::NV; ++j) { const float d = v[j] - mu; q += d * d; }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+      const float sub = a.with_bias ? mu : 0.f;        // BiasFree: x / sqrt(var + eps), x not centred (Restormer.py:37-39)
+#pragma unroll
+      for (int j = 0; j < K::NV; ++j) v[j] = (v[j] - sub) * rstd;
+#pragma unroll
+      for (int ks = 0; ks < K::KS32; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xa[i][ks][j] = bf_bits(v[8 * ks + j]);
+      if (K::KT16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xt[i][j] = bf_bits(v[8 * K::KS32 + j]);
+      // statistics of the tile's own pixels (each image pixel is the centre pixel of exactly one tile)
+      if (a.mean && g == 0) {
+        const int ipx = mt * 16 + li;
+        if (ipx < K::BODY) {
+          const int rr = ipx >> 6, col = ipx & 63;
+          if (rr >= 1 && rr <= TH) {
+            const int64_t o = (int64_t)b * HW + (int64_t)(y0 - 1 + rr) * a.W + x0 + col;
+            a.mean[o] = mu; a.rstd[o] = rstd;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ipx = mt * 16 + 4 * g + r;
+        bool ok;
+        if (ipx < K::BODY) { const int Y = y0 - 1 + (ipx >> 6); ok = Y >= 0 && Y < a.H; }
+        else if (ipx < K::HPX) {
+          const int k = ipx - K::BODY, side = k >= K::HR ? 1 : 0, rr = k - side * K::HR;
+          const int Y = y0 - 1 + rr, X = side ? x0 + 64 : x0 - 1;
+          ok = Y >= 0 && Y < a.H && X >= 0 && X < a.W;
+        } else ok = false;
+        vmask |= (ok ? 1ull : 0ull) << (4 * i + r);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < K::KS32; ++ks) xa[i][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      xt[i] = (s16x4){0, 0, 0, 0};
+    }
+  }
+  if ((a.dbg & 15) == 1) {                                    // debug: LN output of tile 0 as [pixel][channel] bf16
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < K::MTW; ++i) {
+        const int mt = wv + 8 * i;
+        if (mt < K::MT) {
+          bf16* o = a.out + (int64_t)(mt * 16 + li) * C;
+#pragma unroll
+          for (int ks = 0; ks < K::KS32; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              reinterpret_cast<short*>(o)[ks * 32 + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4)] = xa[i][ks][j];
+          if (K::KT16)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reinterpret_cast<short*>(o)[K::KS32 * 32 + 4 * g + j] = xt[i][j];
+        }
+      }
+    }
+    return;
+  }
+  __syncthreads();                                     // the staged y is dead: the region becomes h0 / g / weights
+
+  constexpr int W1V = K::W1_BYTES / 16, W2V = K::W2_BYTES / 16;
+  constexpr int W1N = (W1V + 511) / 512, W2N = (W2V + 511) / 512;
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.w1p);
+    for (int v = t; v < W1V; v += 512) reinterpret_cast<u32x4*>(W1)[v] = src[v];
+  }
+  __syncthreads();
+
+  if ((a.dbg & 15) == 4) {                             // debug: W_in' chunk 0 as staged in LDS [2PC][W1S]
+    if (blockIdx.x == 0)
+      for (int e = t; e < 2 * PC * K::W1S; e += 512) a.out[e] = W1[e];
+    return;
+  }
+  f32x4 acc[K::RP][4][K::CT];
+#pragma unroll
+  for (int j = 0; j < K::RP; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c < a.nch; ++c) {
+    // ------------------------------------------------------------ GEMM1: h0 chunk = W_in'[chunk] . LN(y), to LDS
+    {
+      const float* b1c = a.b1p + (int64_t)c * 2 * PC;
+#pragma unroll
+      for (int nt = 0; nt < K::NT1; ++nt) {
+        const int row = nt * 16 + li;
+        const bf16* wr = &W1[row * K::W1S + 4 * g];
+        s16x8 bw[K::KS32 > 0 ? K::KS32 : 1];
+        s16x4 bt = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < K::KS32; ++ks)
+          bw[ks] = cat8(*reinterpret_cast<const s16x4*>(wr + ks * 32), *reinterpret_cast<const s16x4*>(wr + ks * 32 + 16));
+        if (K::KT16) bt = *reinterpret_cast<const s16x4*>(wr + K::KS32 * 32);
+        const float bias = b1c[row];
+        bf16* hrow = &H0[row * K::PLANE + 4 * g];
+#pragma unroll
+        for (int i = 0; i < K::MTW; ++i) {
+          const int mt = wv + 8 * i;
+          if (mt < K::MT) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < K::KS32; ++ks) d = mfma32(xa[i][ks], bw[ks], d);
+            // a 16-deep tail rides in a zero-padded 32-deep MFMA: a dependent chain that mixes the 16x16x32 and
+            // 16x16x16 shapes returned garbage accumulators on gfx950 (ROCm 7.2) - one opcode per accumulator chain
+            if (K::KT16) d = mfma32(cat8(xt[i], (s16x4){0, 0, 0, 0}), cat8(bt, (s16x4){0, 0, 0, 0}), d);
+            const unsigned m = (unsigned)(vmask >> (4 * i));
+            u32x2 o;
+            o[0] = pack_bf2((m & 1u) ? d[0] + bias : 0.f, (m & 2u) ? d[1] + bias : 0.f);
+            o[1] = pack_bf2((m & 4u) ? d[2] + bias : 0.f, (m & 8u) ? d[3] + bias : 0.f);
+            *reinterpret_cast<u32x2*>(hrow + mt * 16) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if ((a.dbg & 15) == 2) {                                  // debug: h0 chunk 0 of tile 0 as [2PC][HPXP]
+      if (blockIdx.x == 0)
+        for (int e = t; e < 2 * PC * K::HPXP; e += 512) a.out[e] = H0[(e / K::HPXP) * K::PLANE + e % K::HPXP];
+      return;
+    }
+
+    // ------------------------------------------------------------ depthwise 3x3 + GELU gate, VALU; weights for the next GEMMs in flight
+    {
+      u32x4 wr1[W1N], wr2[W2N];
+      const bool more = c + 1 < a.nch;
+      {
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.w1p + (int64_t)(c + 1) * 2 * PC * K::W1S);
+        const u32x4* s2 = reinterpret_cast<const u32x4*>(a.w2p + (int64_t)c * C * K::W2S);
+#pragma unroll
+        for (int n = 0; n < W1N; ++n) { const int v = t + 512 * n; if (more && v < W1V) wr1[n] = s1[v]; }
+#pragma unroll
+        for (int n = 0; n < W2N; ++n) { const int v = t + 512 * n; if (v < W2V) wr2[n] = s2[v]; }
+      }
+      const int cg = lane & 7;
+#pragma unroll 1
+      for (int s = 0; s < K::PPW; ++s) {
+        const int p = wv * K::PPW + s;
+        const float* wp = a.wdp + ((int64_t)c * PC + p) * 20;
+        f32x2 w[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          w[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i])));
+          w[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i + 1])));
+        }
+        const bf16* h1 = &H0[p * K::PLANE];
+        const bf16* h2 = &H0[(PC + p) * K::PLANE];
+        const int eoff = K::BODY + (cg == 7 ? K::HR : 0);
+#pragma unroll
+        for (int rp = 0; rp < K::RP; ++rp) {
+          const int row = rp * 8 + (lane >> 3);
+          f32x2 o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = w[9];
+#pragma unroll
+          for (int dr = 0; dr < 3; ++dr) {
+            const int rin = row + dr;
+            const u32x4 r1 = *reinterpret_cast<const u32x4*>(h1 + rin * 64 + 8 * cg);
+            const u32x4 r2 = *reinterpret_cast<const u32x4*>(h2 + rin * 64 + 8 * cg);
+            const u16 e1 = reinterpret_cast<const u16*>(h1)[eoff + rin];
+            const u16 e2 = reinterpret_cast<const u16*>(h2)[eoff + rin];
+            f32x2 v[10];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[1 + 2 * k][0] = bf_lo(r1[k]); v[2 + 2 * k][0] = bf_hi(r1[k]);
+              v[1 + 2 * k][1] = bf_lo(r2[k]); v[2 + 2 * k][1] = bf_hi(r2[k]);
+            }
+            f32x2 edge, lft, rgt;
+            edge[0] = bf_lo(e1); edge[1] = bf_lo(e2);
+            lft[0] = from_prev_lane(v[8][0]); lft[1] = from_prev_lane(v[8][1]);
+            rgt[0] = from_next_lane(v[1][0]); rgt[1] = from_next_lane(v[1][1]);
+            v[0] = cg == 0 ? edge : lft;
+            v[9] = cg == 7 ? edge : rgt;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) o[j] += w[dr * 3 + kx] * v[j + kx];
+          }
+          float gg[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gg[j] = gelu_erf(o[j][0]) * o[j][1];
+          Vec<bf16, 8>::st(&G[p * K::GS + row * 64 + 8 * cg], gg);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < W1N; ++n) { const int v = t + 512 * n; if (more && v < W1V) reinterpret_cast<u32x4*>(W1)[v] = wr1[n]; }
+#pragma unroll
+      for (int n = 0; n < W2N; ++n) { const int v = t + 512 * n; if (v < W2V) reinterpret_cast<u32x4*>(W2)[v] = wr2[n]; }
+    }
+    __syncthreads();
+    if ((a.dbg & 15) == 3) {                                  // debug: gate output chunk 0 of tile 0 as [PC][TH*64]
+      if (blockIdx.x == 0)
+        for (int e = t; e < PC * TH * 64; e += 512) a.out[e] = G[(e / (TH * 64)) * K::GS + e % (TH * 64)];
+      return;
+    }
+
+    // ------------------------------------------------------------ GEMM2: acc[tile rows of this wave][C] += g^T . W_out[chunk]^T
+    {
+      s16x8 bo8[K::CT];
+      s16x4 bo4[K::CT];
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) {
+        const bf16* wr = &W2[(ct * 16 + li) * K::W2S + 4 * g];
+        if (PC == 32) bo8[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), *reinterpret_cast<const s16x4*>(wr + 16));
+        else bo4[ct] = *reinterpret_cast<const s16x4*>(wr);
+      }
+#pragma unroll
+      for (int j = 0; j < K::RP; ++j) {
+        const bf16* gp = &G[(4 * g + qq) * K::GS + (wv + 8 * j) * 64 + 4 * pp];
+        s16x4 lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          lo[q] = tr_b16(gp + 16 * q);
+          hi[q] = PC == 32 ? tr_b16(gp + 16 * K::GS + 16 * q) : lo[q];
+        }
+        lds_wait(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int ct = 0; ct < K::CT; ++ct) {
+            if (PC == 32) acc[j][q][ct] = mfma32(cat8(lo[q], hi[q]), bo8[ct], acc[j][q][ct]);
+            else acc[j][q][ct] = mfma32(cat8(lo[q], (s16x4){0, 0, 0, 0}), cat8(bo4[ct], (s16x4){0, 0, 0, 0}), acc[j][q][ct]);
+          }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: + bias + residual y, whole 128-byte rows
+  // (wave-private fp32 slab inside the h0 region: nobody reads h0 after the last barrier)
+  {
+    float* slab = reinterpret_cast<float*>(fg_lds) + wv * 16 * K::SLAB_OS;
+    const int e_row = lane >> 3, e_col = (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < K::RP; ++j) {
+      const int64_t pix = (int64_t)(y0 + wv + 8 * j) * a.W + x0 + e_col;
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) {
+        u32x4 rr[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          rr[it] = *reinterpret_cast<const u32x4*>(yb + (int64_t)(ct * 16 + it * 8 + e_row) * HW + pix);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4] = {acc[j][q][ct][0], acc[j][q][ct][1], acc[j][q][ct][2], acc[j][q][ct][3]};
+          Vec<float, 4>::st(&slab[li * K::SLAB_OS + 16 * q + 4 * g], v);
+        }
+        wave_sync();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int m = ct * 16 + it * 8 + e_row;
+          float v[8];
+          Vec<float, 4>::ld(&slab[(it * 8 + e_row) * K::SLAB_OS + e_col], v);
+          Vec<float, 4>::ld(&slab[(it * 8 + e_row) * K::SLAB_OS + e_col + 4], v + 4);
+          const float bv = a.b2[m];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += bv + bf_lo(rr[it][k]);
+            v[2 * k + 1] += bv + bf_hi(rr[it][k]);
+          }
+          Vec<bf16, 8>::st(a.out + ((int64_t)b * C + m) * HW + pix, v);
+        }
+        wave_sync();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+enum FgKind { FG_NONE = 0, FG_C48, FG_C96 };
+// A/B switch (read per call): MI_FG_CFG=th8 runs C = 48 on 8-row tiles, MI_FG_CFG=pc16 / pc32 overrides the pairs per chunk
+static int fg_cfg_th(int C, int H) {
+  const char* e = getenv("MI_FG_CFG");
+  if (C == 48 && !(e && strstr(e, "th8")) && H % 16 == 0) return 16;
+  return 8;
+}
+static int fg_cfg_pc(int C, int th) {
+  const char* e = getenv("MI_FG_CFG");
+  if (e && strstr(e, "pc16")) return 16;
+  if (e && strstr(e, "pc32") && th == 8) return 32;
+  return (C == 48 && th == 16) ? 16 : 32;
+}
+static FgKind fg_kind(const mi_gdfn_fused_shape* s) {
+  if (!s || s->B <= 0 || s->hidden <= 0) return FG_NONE;
+  if (s->W % 64 != 0 || s->H % 8 != 0) return FG_NONE;
+  if (s->C == 48) return FG_C48;
+  if (s->C == 96) return FG_C96;
+  return FG_NONE;
+}
+
+template <int C, int TH, int PC>
+static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const void* pack, const void* y, void* out,
+                     float* mean, float* rstd, hipStream_t st) {
+  using K = FgCfg<C, TH, PC>;
+  FgArgs a;
+  const unsigned char* pk = (const unsigned char*)pack;
+  a.y = (const bf16*)y; a.out = (bf16*)out; a.mean = mean; a.rstd = rstd;
+  a.w1p = (const bf16*)(pk + l.w1p); a.w2p = (const bf16*)(pk + l.w2p); a.b1p = (const float*)(pk + l.b1p);
+  a.wdp = (const float*)(pk + l.wdp); a.b2 = (const float*)(pk + l.b2);
+  a.B = s->B; a.H = s->H; a.W = s->W; a.nch = l.nch; a.with_bias = s->ln_with_bias;
+  a.tiles_x = s->W / 64; a.tiles_y = s->H / TH;
+  { const char* e = getenv("MI_FG_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  const int64_t tiles = (int64_t)s->B * a.tiles_x * a.tiles_y;
+  MI_CHECK_ARG(tiles < (1ll << 31), "gdfn_fused: grid too large");
+  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, PC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)K::LDS_BYTES));
+  const double N = (double)s->H * s->W * s->B, h = s->hidden;
+  ProfScope ps(st, K_GDFN_FUSED_FWD, 2.0 * C * N * 2.0, 2.0 * N * (3.0 * C * h) + 2.0 * N * 9.0 * 2.0 * h);
+  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, PC>), dim3((unsigned)tiles), dim3(512), K::LDS_BYTES, st, a);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" int mi_gdfn_fused_ok(const mi_gdfn_fused_shape* s) { return fg_kind(s) != FG_NONE ? 1 : 0; }
+
+extern "C" size_t mi_gdfn_fused_pack_bytes(const mi_gdfn_fused_shape* s) {
+  const FgKind k = fg_kind(s);
+  if (k == FG_NONE) return 0;
+  return fg_pack_layout(s->C, s->hidden, 16).bytes > fg_pack_layout(s->C, s->hidden, 32).bytes
+             ? fg_pack_layout(s->C, s->hidden, 16).bytes : fg_pack_layout(s->C, s->hidden, 32).bytes;
+}
+
+extern "C" int mi_gdfn_fused_pack(const mi_gdfn_fused_shape* s, const float* ln_w, const float* ln_b,
+                                  const mi_gdfn_params* p, void* pack, void* stream) {
+  const FgKind k = fg_kind(s);
+  MI_CHECK_ARG(k != FG_NONE, "gdfn_fused_pack: shape not covered by the fused kernels (mi_gdfn_fused_ok)");
+  MI_CHECK_ARG(ln_w && p && p->in_w && p->dw_w && p->out_w && pack, "gdfn_fused_pack: null pointer");
+  MI_CHECK_ARG((s->ln_with_bias != 0) == (ln_b != nullptr), "gdfn_fused_pack: ln_with_bias does not match ln_b");
+  MI_CHECK_ARG(aligned16(pack), "gdfn_fused_pack: pack buffer must be 16-byte aligned");
+  const int PC = fg_cfg_pc(s->C, fg_cfg_th(s->C, s->H));
+  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, PC);
+  unsigned char* pk = (unsigned char*)pack;
+  FgPackArgs a;
+  a.ln_w = ln_w; a.ln_b = ln_b; a.in_w = p->in_w; a.in_b = p->in_b; a.dw_w = p->dw_w; a.dw_b = p->dw_b;
+  a.out_w = p->out_w; a.out_b = p->out_b;
+  a.w1p = (bf16*)(pk + l.w1p); a.w2p = (bf16*)(pk + l.w2p); a.b1p = (float*)(pk + l.b1p); a.wdp = (float*)(pk + l.wdp);
+  a.b2 = (float*)(pk + l.b2);
+  a.C = s->C; a.h = s->hidden; a.PC = PC; a.nch = l.nch;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_FUSED_PACK, (double)l.bytes, 0.0);
+  hipLaunchKernelGGL(fg_pack_kernel, dim3(128), dim3(256), 0, st, a);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean,
+                                 float* rstd, void* stream) {
+  const FgKind k = fg_kind(s);
+  MI_CHECK_ARG(k != FG_NONE, "gdfn_fused_fwd: shape not covered by the fused kernels (mi_gdfn_fused_ok)");
+  MI_CHECK_ARG(pack && y && out, "gdfn_fused_fwd: null pointer");
+  MI_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "gdfn_fused_fwd: mean and rstd go together");
+  MI_CHECK_ARG(aligned16(pack) && aligned16(y) && aligned16(out), "gdfn_fused_fwd: pointers must be 16-byte aligned");
+  const int th = fg_cfg_th(s->C, s->H), pc = fg_cfg_pc(s->C, th);
+  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, pc);
+  hipStream_t st = (hipStream_t)stream;
+  if (k == FG_C48) {
+    if (th == 16) return fg_launch<48, 16, 16>(s, l, pack, y, out, mean, rstd, st);
+    if (pc == 16) return fg_launch<48, 8, 16>(s, l, pack, y, out, mean, rstd, st);
+    return fg_launch<48, 8, 32>(s, l, pack, y, out, mean, rstd, st);
+  }
+  if (pc == 16) return fg_launch<96, 8, 16>(s, l, pack, y, out, mean, rstd, st);
+  return fg_launch<96, 8, 32>(s, l, pack, y, out, mean, rstd, st);
+}

@@ -325,6 +325,47 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
     return dx
 
 
+# ----------------------------------------------------------------------------- fused half-blocks (bf16)
+def _gdfn_fused_shape(x: Tensor, hidden: int, with_bias: bool) -> L.GdfnFusedShape:
+    B, Cc, H, W = x.shape
+    return L.GdfnFusedShape(B, Cc, hidden, H, W, int(with_bias))
+
+
+def gdfn_fused_ok(x: Tensor, hidden: int, ks: int = 3) -> bool:
+    """True when the one-launch LN + GDFN + residual kernel covers this activation (bf16, 3x3, tile-aligned)."""
+    if x.dtype != torch.bfloat16 or ks != 3 or not x.is_cuda:
+        return False
+    s = _gdfn_fused_shape(x, hidden, True)
+    return bool(L.lib().mi_gdfn_fused_ok(C.byref(s)))
+
+
+def gdfn_fused_pack(x_like: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], params: "GdfnParamsT") -> Tensor:
+    """LayerNorm affine + GDFN parameters -> the fused kernel's packed weight images (re-run after weight updates)."""
+    _gpu(ln_w, ln_b, *params)
+    for t in (ln_w, ln_b) + tuple(params):
+        _f32(t, "fused GDFN parameter")
+    hidden = params[4].shape[1]
+    s = _gdfn_fused_shape(x_like, hidden, ln_b is not None)
+    lib = L.lib()
+    pack = _blob(lib.mi_gdfn_fused_pack_bytes(C.byref(s)), ln_w.device)
+    pp = L.GdfnParams(*[_p(t) for t in params])
+    L.check(lib.mi_gdfn_fused_pack(C.byref(s), _p(ln_w), _p(ln_b), C.byref(pp), _p(pack), _stream()), "gdfn_fused_pack")
+    return pack
+
+
+def gdfn_fused_fwd(y: Tensor, pack: Tensor, hidden: int, with_bias: bool, want_stats: bool = False):
+    """out = y + GDFN(LN(y)) in one launch; optionally the LN statistics [B, H*W] of y."""
+    _gpu(y, pack)
+    s = _gdfn_fused_shape(y, hidden, with_bias)
+    out = torch.empty_like(y)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((y.shape[0], y.shape[2] * y.shape[3]), dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+    L.check(L.lib().mi_gdfn_fused_fwd(C.byref(s), _p(pack), _p(y), _p(out), _p(mean), _p(rstd), _stream()), "gdfn_fused_fwd")
+    return out, mean, rstd
+
+
 # ----------------------------------------------------------------------------- router GAP
 def rows_gather(x: Tensor, idx: Tensor) -> Tensor:
     """out[i] = x[idx[i]] over whole [C,H,W] rows (SparseDispatcher.dispatch)."""

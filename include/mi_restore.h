@@ -222,6 +222,26 @@ int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, 
                 void* dx, const mi_gdfn_grads* g, const void* saved, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fused GDFN half-block (bf16 activations):  out = y + FeedForward(LayerNorm(y))
+ * = the second half of TransformerBlock.forward (Restormer.py:148 `x = x + self.ffn(self.norm2(x))`;
+ * moce_ir.py:834 EncoderBlock; AdaIR-main/net/model.py:170) as ONE kernel: y is read once (plus a
+ * one-pixel halo), out is written once; LN output, project_in output, conv outputs and the gate never
+ * reach HBM.  Covered shapes (mi_gdfn_fused_ok): 3x3 depthwise, W % 64 == 0, H % 8 == 0, C = 48 or 96;
+ * any hidden size.  Other shapes use mi_ln_fwd + mi_gdfn_fwd.
+ *   mi_gdfn_fused_pack : LayerNorm weight/bias + the six GDFN parameters -> the kernel's packed bf16/fp32
+ *                        weight images (LN affine folded into project_in).  Re-run after every weight update.
+ *   mi_gdfn_fused_fwd  : y, out [B,C,H,W] bf16; mean/rstd [B,H*W] fp32 (both or neither; LN statistics of y
+ *                        for the backward pass).
+ * ------------------------------------------------------------------------ */
+typedef struct { int B, C, hidden, H, W, ln_with_bias; } mi_gdfn_fused_shape;
+int mi_gdfn_fused_ok(const mi_gdfn_fused_shape* s);
+size_t mi_gdfn_fused_pack_bytes(const mi_gdfn_fused_shape* s);
+int mi_gdfn_fused_pack(const mi_gdfn_fused_shape* s, const float* ln_w, const float* ln_b, const mi_gdfn_params* p,
+                       void* pack, void* stream);
+int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean,
+                      float* rstd, void* stream);
+
+/* ------------------------------------------------------------------------
  * Training-step tail on flat fp32 buffers (MoCE-IR-main/src/train.py:79-88:
  * AdamW(lr=2e-4), torch defaults betas (0.9,0.999), eps 1e-8, weight_decay 1e-2).
  * p, g, m, v: [n] fp32.  grad_scale multiplies g first (1/world for DDP mean).

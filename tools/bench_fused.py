@@ -1,0 +1,54 @@
+"""Micro-benchmark of the fused half-block kernels against the unfused kernel chain they replace, at the Restormer-base
+training planes (BF_BATCH images, bf16).  Run on the GPU box: python tools/bench_fused.py [gdfn|mdta]."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_restoration_amd import ops  # noqa: E402
+
+DEV = "cuda"
+B = int(os.environ.get("BF_BATCH", "32"))
+SHAPES = [(48, 256, 256, 127), (96, 128, 128, 255), (96, 256, 256, 255)]
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def gdfn():
+    for C, H, W, h in SHAPES:
+        torch.manual_seed(0)
+        y = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16)
+        ln_w = 1 + 0.1 * torch.randn(C, device=DEV)
+        ln_b = 0.1 * torch.randn(C, device=DEV)
+        params = (torch.randn(2 * h, C, 1, 1, device=DEV) / C ** 0.5, None, torch.randn(2 * h, 1, 3, 3, device=DEV) / 3, None,
+                  torch.randn(C, h, 1, 1, device=DEV) / h ** 0.5, None)
+        pack = ops.gdfn_fused_pack(y, ln_w, ln_b, params)
+        fused = lambda: ops.gdfn_fused_fwd(y, pack, h, True, want_stats=True)
+
+        def chain():
+            yn, _, _ = ops.ln_fwd(y, ln_w, ln_b, True, want_stats=True)
+            ops.gdfn_fwd(yn, y, params, True)
+
+        tf, tc = timeit(fused), timeit(chain)
+        nbytes = 2.0 * B * C * H * W * 2
+        flops = 2.0 * B * H * W * 3 * C * h
+        print(f"gdfn fwd C={C} {H}x{W} h={h} bs={B}: fused {tf:8.1f} us ({nbytes / tf / 1e6:6.2f} TB/s alg, "
+              f"{flops / tf / 1e6:6.1f} TF/s)   chain {tc:8.1f} us   speed-up {tc / tf:4.2f}x", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "gdfn"
+    {"gdfn": gdfn}[which]()
