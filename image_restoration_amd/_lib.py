@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi_restore.so")
+LIB_PATH = os.environ.get("MI_RESTORE_LIB") or os.path.join(HERE, "libmi_restore.so")   # (override: A/B builds)
 
 MI_F32, MI_BF16 = 0, 1
 c_i64 = C.c_int64

@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .restormer import (Attention, FeedForward, LayerNorm, TransformerBlock, _CrossAttentionFn)  # noqa: F401
+from .restormer import (Attention, FeedForward, LayerNorm, TransformerBlock, _apply, _CrossAttentionFn)  # noqa: F401
 
 __all__ = ["Attention", "FeedForward", "LayerNorm", "TransformerBlock", "Chanel_Cross_Attention"]
 
@@ -31,4 +31,4 @@ class Chanel_Cross_Attention(nn.Module):
     def forward(self, x, y):
         # x -> q, y -> kv
         assert x.shape == y.shape, 'The shape of feature maps from image and features are not equal!'
-        return _CrossAttentionFn.apply(x, y, self.num_head, *self._params())
+        return _apply(_CrossAttentionFn, x, y, self.num_head, *self._params())

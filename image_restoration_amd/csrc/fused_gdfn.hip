@@ -25,52 +25,66 @@
 namespace mi {
 using namespace fz;
 
-template <int C_, int TH_, int PC_> struct FgCfg {
-  static constexpr int C = C_, TH = TH_, PC = PC_;
+template <int C_, int TH_, int TW_, int PC_, int NW_> struct FgCfg {
+  static constexpr int C = C_, TH = TH_, TW = TW_, PC = PC_, NW = NW_;
+  static constexpr int NT = 64 * NW;                   // threads per workgroup
   static constexpr int HR = TH + 2;
-  static constexpr int BODY = HR * 64;
+  static constexpr int BODY = HR * TW;
   static constexpr int HPX = BODY + 2 * HR;
   static constexpr int HPXP = (HPX + 15) / 16 * 16;
   static constexpr int MT = HPXP / 16;                 // 16-pixel m-tiles of GEMM1
-  static constexpr int MTW = (MT + 7) / 8;             // per wave
+  static constexpr int MTW = (MT + NW - 1) / NW;       // per wave
   static constexpr int PLANE = (HPXP % 16 == 8) ? HPXP : HPXP + 8;   // plane stride (elements): 16-byte aligned planes
   static constexpr int KS32 = C / 32, KT16 = (C % 32) / 16;
   static constexpr int NV = 8 * KS32 + 4 * KT16;       // channel values per lane per pixel (C / 4)
   static constexpr int W1S = C + 8;                    // LDS row strides (elements): conflict-free 8-byte operand reads
   static constexpr int W2S = PC + 8;
-  static constexpr int GS = TH * 64 + 16;              // g row stride: conflict-free transposed reads
+  static constexpr int GS = TH * TW + 16;              // g row stride: conflict-free transposed reads
   static constexpr int NT1 = 2 * PC / 16;              // 16-channel n-tiles of GEMM1
   static constexpr int CT = C / 16;                    // 16-channel tiles of the output
-  static constexpr int RP = TH / 8;                    // tile rows per wave (and conv row passes)
-  static constexpr int PPW = PC / 8;                   // gate pairs per wave per chunk
+  static constexpr int VPR = TW / 8;                   // 16-byte vectors per tile row
+  static constexpr int QT = TW / 16;                   // 16-pixel tiles per tile row
+  static constexpr int RPW = TH / NW;                  // tile rows owned by a wave (GEMM2 / epilogue)
+  // conv phase: a lane owns 8 pixels of one row; a wave covers ROWS rows of NPAIR gate pairs per pass
+  static constexpr int CG = TW / 8;
+  static constexpr int RPP = 64 / CG;
+  static constexpr int ROWS = TH < RPP ? TH : RPP;
+  static constexpr int NPAIR = RPP / ROWS;
+  static constexpr int PASSES = TH / ROWS;
+  static constexpr int PPW = PC / NW;                  // gate pairs per wave per chunk
   static constexpr int H0_BYTES = 2 * PC * PLANE * 2;
   static constexpr int G_BYTES = PC * GS * 2;
   static constexpr int W1_BYTES = 2 * PC * W1S * 2;
   static constexpr int W2_BYTES = C * W2S * 2;
+  static constexpr int WD_BYTES = PC * 20 * 4;         // depthwise taps + bias of a chunk, fp32 (two buffers)
   static constexpr int S_BYTES = C * PLANE * 2;        // prologue: raw y staged plane-major (aliases everything)
-  static constexpr int MAIN_BYTES = H0_BYTES + G_BYTES + W1_BYTES + W2_BYTES;
+  static constexpr int MAIN_BYTES = H0_BYTES + G_BYTES + W1_BYTES + W2_BYTES + 2 * WD_BYTES;
   static constexpr int LDS_BYTES = MAIN_BYTES > S_BYTES ? MAIN_BYTES : S_BYTES;
-  static constexpr int SLAB_OS = 68;                   // epilogue: wave-private fp32 slab [16 ch][64 px + pad]
-  static_assert(C % 16 == 0 && TH % 8 == 0 && PC % 8 == 0 && (PC == 16 || PC == 32), "unsupported tile");
-  static_assert(8 * 16 * SLAB_OS * 4 <= H0_BYTES, "epilogue slabs live in the h0 region");
+  static constexpr int SLAB_OS = TW + 4;               // epilogue: wave-private fp32 slab [16 ch][TW px + pad]
+  static constexpr int LPR = TW / 8;                   // epilogue: lanes per output row
+  static constexpr int RPI = 64 / LPR;                 // rows per store instruction
+  static constexpr int ITS = 16 / RPI;
+  static_assert(C % 16 == 0 && (TW == 32 || TW == 64) && (PC == 16 || PC == 32) && (NW == 4 || NW == 8), "unsupported tile");
+  static_assert(TH % NW == 0 && TH % ROWS == 0 && PPW % NPAIR == 0 && PC % NW == 0, "tile rows / pairs must split over the waves");
+  static_assert(GS % 128 == 16, "g row stride");
+  static_assert(NW * 16 * SLAB_OS * 4 <= H0_BYTES, "epilogue slabs live in the h0 region");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct FgArgs {
   const bf16* y; bf16* out; float* mean; float* rstd;
-  const bf16* w1p; const bf16* w2p; const float* b1p; const float* wdp; const float* b2;
-  int B, H, W, nch, with_bias, tiles_x, tiles_y, dbg;
+  const bf16* w1p; const bf16* w2p; const float* wdp; const float* b2;
+  int B, H, W, nch, with_bias, tiles_x, tiles_y, dbg, xcd_pairs;
 };
 
 // packed-weight blob layout (bytes from its base), shared by the pack kernel and the launcher
-struct FgPackLayout { size_t w1p, w2p, b1p, wdp, b2, bytes; int nch; };
+struct FgPackLayout { size_t w1p, w2p, wdp, b2, bytes; int nch; };
 static FgPackLayout fg_pack_layout(int C, int hidden, int PC) {
   FgPackLayout l;
   l.nch = cdiv(hidden, PC);
   size_t off = 0;
   l.w1p = off; off = align_up(off + (size_t)l.nch * 2 * PC * (C + 8) * 2, 256);
   l.w2p = off; off = align_up(off + (size_t)l.nch * C * (PC + 8) * 2, 256);
-  l.b1p = off; off = align_up(off + (size_t)l.nch * 2 * PC * 4, 256);
   l.wdp = off; off = align_up(off + (size_t)l.nch * PC * 20 * 4, 256);
   l.b2 = off; off = align_up(off + (size_t)C * 4, 256);
   l.bytes = off;
@@ -79,23 +93,34 @@ static FgPackLayout fg_pack_layout(int C, int hidden, int PC) {
 
 struct FgPackArgs {
   const float *ln_w, *ln_b, *in_w, *in_b, *dw_w, *dw_b, *out_w, *out_b;
-  bf16* w1p; bf16* w2p; float* b1p; float* wdp; float* b2;
+  bf16* w1p; bf16* w2p; float* wdp; float* b2;
   int C, h, PC, nch;
 };
 
 __global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
   const int C = a.C, h = a.h, PC = a.PC, W1S = C + 8, W2S = PC + 8;
-  const int64_t n_w1 = (int64_t)a.nch * 2 * PC * W1S, n_w2 = (int64_t)a.nch * C * W2S, n_b1 = (int64_t)a.nch * 2 * PC,
+  const int64_t n_w1 = (int64_t)a.nch * 2 * PC * W1S, n_w2 = (int64_t)a.nch * C * W2S,
                 n_wd = (int64_t)a.nch * PC * 20, n_b2 = C;
-  const int64_t total = n_w1 + n_w2 + n_b1 + n_wd + n_b2;
+  const int64_t total = n_w1 + n_w2 + n_wd + n_b2;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     int64_t r = e;
     if (r < n_w1) {                                   // W_in'[chunk][row][k] = W_in[hidden row][k] * gamma[k]
       const int k = (int)(r % W1S); r /= W1S;
       const int rr = (int)(r % (2 * PC)), c = (int)(r / (2 * PC));
       const int jl = c * PC + rr % PC, hid = (rr / PC) * h + jl;
-      const float v = (k < C && jl < h) ? a.in_w[(int64_t)hid * C + k] * a.ln_w[k] : 0.f;
-      a.w1p[e] = (bf16)v;
+      if (k < C) {
+        a.w1p[e] = (bf16)(jl < h ? a.in_w[(int64_t)hid * C + k] * a.ln_w[k] : 0.f);
+      } else if (k == C) {                            // the row's fp32 bias b' = b_in + W_in . beta rides in the row padding
+        float sb = 0.f;
+        if (jl < h) {
+          sb = a.in_b ? a.in_b[hid] : 0.f;
+          if (a.ln_b)
+            for (int kk = 0; kk < C; ++kk) sb += a.in_w[(int64_t)hid * C + kk] * a.ln_b[kk];
+        }
+        *reinterpret_cast<float*>(&a.w1p[e]) = sb;
+      } else if (k >= C + 2) {
+        a.w1p[e] = (bf16)0.f;
+      }
       continue;
     }
     r -= n_w1;
@@ -107,19 +132,6 @@ __global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
       continue;
     }
     r -= n_w2;
-    if (r < n_b1) {                                   // b' = b_in + W_in . beta
-      const int rr = (int)(r % (2 * PC)), c = (int)(r / (2 * PC));
-      const int jl = c * PC + rr % PC, hid = (rr / PC) * h + jl;
-      float s = 0.f;
-      if (jl < h) {
-        s = a.in_b ? a.in_b[hid] : 0.f;
-        if (a.ln_b)
-          for (int k = 0; k < C; ++k) s += a.in_w[(int64_t)hid * C + k] * a.ln_b[k];
-      }
-      a.b1p[r] = s;
-      continue;
-    }
-    r -= n_b1;
     if (r < n_wd) {                                   // [chunk][pair][tap 0..8, bias][half]
       const int half = (int)(r % 2); int64_t q = r / 2;
       const int tp = (int)(q % 10); q /= 10;
@@ -135,47 +147,72 @@ __global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
   }
 }
 
-template <int C, int TH, int PC>
-__global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
-  using K = FgCfg<C, TH, PC>;
+template <int C, int TH, int TW, int PC, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
+  using K = FgCfg<C, TH, TW, PC, NW>;
+  constexpr int NT = K::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char fg_lds[];
   bf16* const H0 = reinterpret_cast<bf16*>(fg_lds);
   bf16* const G = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES);
   bf16* const W1 = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES + K::G_BYTES);
   bf16* const W2 = reinterpret_cast<bf16*>(fg_lds + K::H0_BYTES + K::G_BYTES + K::W1_BYTES);
+  float* const WD = reinterpret_cast<float*>(fg_lds + K::H0_BYTES + K::G_BYTES + K::W1_BYTES + K::W2_BYTES);   // [2][PC][20]
   bf16* const S = reinterpret_cast<bf16*>(fg_lds);
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
   int bid = blockIdx.x;
+  if (a.xcd_pairs) {                                   // x-adjacent 32-pixel tiles (the two halves of 128-byte lines) on one XCD
+    const int q16 = bid >> 4, r16 = bid & 15;
+    bid = 2 * (8 * q16 + (r16 & 7)) + (r16 >> 3);
+  }
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
-  const int x0 = tx * 64, y0 = ty * TH;
+  const int x0 = tx * TW, y0 = ty * TH;
   const int64_t HW = (int64_t)a.H * a.W;
   const bf16* const yb = a.y + (int64_t)b * C * HW;
 
   // ---------------------------------------------------------------- prologue: stage raw y (tile + halo), plane-major
   {
-    constexpr int NB = C * K::HR * 8;                  // 16-byte vectors of the tile body
-    for (int idx = t; idx < NB; idx += 512) {
-      const int c = idx / (K::HR * 8), rem = idx - c * (K::HR * 8), r = rem >> 3, u = rem & 7;
-      const int Y = y0 - 1 + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (Y >= 0 && Y < a.H) v = *reinterpret_cast<const u32x4*>(yb + (int64_t)c * HW + (int64_t)Y * a.W + x0 + 8 * u);
-      *reinterpret_cast<u32x4*>(&S[c * K::PLANE + r * 64 + 8 * u]) = v;
-    }
+    constexpr int NB = C * K::HR * K::VPR;             // 16-byte vectors of the tile body
+    constexpr int NBV = (NB + NT - 1) / NT;
     constexpr int NE = K::HPXP - K::BODY;              // halo-column pixels + padding per plane
-    for (int idx = t; idx < C * NE; idx += 512) {
+    constexpr int NEV = (C * NE + NT - 1) / NT;
+    u32x4 raw[NBV];
+    u16 rawe[NEV];
+#pragma unroll
+    for (int n = 0; n < NBV; ++n) {
+      const int idx = t + NT * n;
+      const int c = idx / (K::HR * K::VPR), rem = idx - c * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+      const int Y = y0 - 1 + r;
+      raw[n] = (u32x4){0u, 0u, 0u, 0u};
+      if (idx < NB && Y >= 0 && Y < a.H)
+        raw[n] = *reinterpret_cast<const u32x4*>(yb + (int64_t)c * HW + (int64_t)Y * a.W + x0 + 8 * u);
+    }
+#pragma unroll
+    for (int n = 0; n < NEV; ++n) {
+      const int idx = t + NT * n;
       const int c = idx / NE, k = idx - c * NE;
-      u16 v = 0;
-      if (k < 2 * K::HR) {
+      rawe[n] = 0;
+      if (idx < C * NE && k < 2 * K::HR) {
         const int side = k >= K::HR ? 1 : 0, r = k - side * K::HR;
-        const int Y = y0 - 1 + r, X = side ? x0 + 64 : x0 - 1;
+        const int Y = y0 - 1 + r, X = side ? x0 + TW : x0 - 1;
         if (Y >= 0 && Y < a.H && X >= 0 && X < a.W)
-          v = reinterpret_cast<const u16*>(yb)[(int64_t)c * HW + (int64_t)Y * a.W + X];
+          rawe[n] = reinterpret_cast<const u16*>(yb)[(int64_t)c * HW + (int64_t)Y * a.W + X];
       }
-      reinterpret_cast<u16*>(S)[c * K::PLANE + K::BODY + k] = v;
+    }
+#pragma unroll
+    for (int n = 0; n < NBV; ++n) {
+      const int idx = t + NT * n;
+      const int c = idx / (K::HR * K::VPR), rem = idx - c * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+      if (idx < NB) *reinterpret_cast<u32x4*>(&S[c * K::PLANE + r * TW + 8 * u]) = raw[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NEV; ++n) {
+      const int idx = t + NT * n;
+      const int c = idx / NE, k = idx - c * NE;
+      if (idx < C * NE) reinterpret_cast<u16*>(S)[c * K::PLANE + K::BODY + k] = rawe[n];
     }
   }
   __syncthreads();
@@ -185,9 +222,10 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
   s16x8 xa[K::MTW][K::KS32 > 0 ? K::KS32 : 1];
   s16x4 xt[K::MTW];
   unsigned long long vmask = 0;                        // bit 4i + r: pixel r of this lane's row group in m-tile i is inside the image
+  static_assert(4 * K::MTW <= 64, "validity mask");
 #pragma unroll
   for (int i = 0; i < K::MTW; ++i) {
-    const int mt = wv + 8 * i;
+    const int mt = wv + NW * i;
     if (mt < K::MT) {
       const bf16* sp = &S[(4 * g + qq) * K::PLANE + mt * 16 + 4 * pp];
       s16x4 lo[K::KS32 > 0 ? K::KS32 : 1], hi[K::KS32 > 0 ? K::KS32 : 1], tl = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
       if (a.mean && g == 0) {
         const int ipx = mt * 16 + li;
         if (ipx < K::BODY) {
-          const int rr = ipx >> 6, col = ipx & 63;
+          const int rr = ipx / TW, col = ipx % TW;
           if (rr >= 1 && rr <= TH) {
             const int64_t o = (int64_t)b * HW + (int64_t)(y0 - 1 + rr) * a.W + x0 + col;
             a.mean[o] = mu; a.rstd[o] = rstd;
@@ -246,10 +284,10 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int ipx = mt * 16 + 4 * g + r;
         bool ok;
-        if (ipx < K::BODY) { const int Y = y0 - 1 + (ipx >> 6); ok = Y >= 0 && Y < a.H; }
+        if (ipx < K::BODY) { const int Y = y0 - 1 + ipx / TW; ok = Y >= 0 && Y < a.H; }
         else if (ipx < K::HPX) {
           const int k = ipx - K::BODY, side = k >= K::HR ? 1 : 0, rr = k - side * K::HR;
-          const int Y = y0 - 1 + rr, X = side ? x0 + 64 : x0 - 1;
+          const int Y = y0 - 1 + rr, X = side ? x0 + TW : x0 - 1;
           ok = Y >= 0 && Y < a.H && X >= 0 && X < a.W;
         } else ok = false;
         vmask |= (ok ? 1ull : 0ull) << (4 * i + r);
@@ -260,11 +298,11 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
       xt[i] = (s16x4){0, 0, 0, 0};
     }
   }
-  if ((a.dbg & 15) == 1) {                                    // debug: LN output of tile 0 as [pixel][channel] bf16
+  if ((a.dbg & 15) == 1) {                             // debug: LN output of tile 0 as [pixel][channel] bf16
     if (blockIdx.x == 0) {
 #pragma unroll
       for (int i = 0; i < K::MTW; ++i) {
-        const int mt = wv + 8 * i;
+        const int mt = wv + NW * i;
         if (mt < K::MT) {
           bf16* o = a.out + (int64_t)(mt * 16 + li) * C;
 #pragma unroll
@@ -282,31 +320,27 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
   }
   __syncthreads();                                     // the staged y is dead: the region becomes h0 / g / weights
 
-  constexpr int W1V = K::W1_BYTES / 16, W2V = K::W2_BYTES / 16;
-  constexpr int W1N = (W1V + 511) / 512, W2N = (W2V + 511) / 512;
+  constexpr int W1V = K::W1_BYTES / 16, W2V = K::W2_BYTES / 16, WDV = K::WD_BYTES / 16;
+  constexpr int W1N = (W1V + NT - 1) / NT, W2N = (W2V + NT - 1) / NT;
+  static_assert(WDV <= NT, "one vector per thread");
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(a.w1p);
-    for (int v = t; v < W1V; v += 512) reinterpret_cast<u32x4*>(W1)[v] = src[v];
+    for (int v = t; v < W1V; v += NT) reinterpret_cast<u32x4*>(W1)[v] = src[v];
+    if (t < WDV) reinterpret_cast<u32x4*>(WD)[t] = reinterpret_cast<const u32x4*>(a.wdp)[t];
   }
   __syncthreads();
 
-  if ((a.dbg & 15) == 4) {                             // debug: W_in' chunk 0 as staged in LDS [2PC][W1S]
-    if (blockIdx.x == 0)
-      for (int e = t; e < 2 * PC * K::W1S; e += 512) a.out[e] = W1[e];
-    return;
-  }
-  f32x4 acc[K::RP][4][K::CT];
+  f32x4 acc[K::RPW][K::QT][K::CT];
 #pragma unroll
-  for (int j = 0; j < K::RP; ++j)
+  for (int j = 0; j < K::RPW; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < K::QT; ++q)
 #pragma unroll
       for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int c = 0; c < a.nch; ++c) {
     // ------------------------------------------------------------ GEMM1: h0 chunk = W_in'[chunk] . LN(y), to LDS
-    {
-      const float* b1c = a.b1p + (int64_t)c * 2 * PC;
+    if (!(a.dbg & 32)) {
 #pragma unroll
       for (int nt = 0; nt < K::NT1; ++nt) {
         const int row = nt * 16 + li;
@@ -317,11 +351,11 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
         for (int ks = 0; ks < K::KS32; ++ks)
           bw[ks] = cat8(*reinterpret_cast<const s16x4*>(wr + ks * 32), *reinterpret_cast<const s16x4*>(wr + ks * 32 + 16));
         if (K::KT16) bt = *reinterpret_cast<const s16x4*>(wr + K::KS32 * 32);
-        const float bias = b1c[row];
+        const float bias = *reinterpret_cast<const float*>(&W1[row * K::W1S + C]);
         bf16* hrow = &H0[row * K::PLANE + 4 * g];
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i) {
-          const int mt = wv + 8 * i;
+          const int mt = wv + NW * i;
           if (mt < K::MT) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -339,49 +373,55 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
       }
     }
     __syncthreads();
-    if ((a.dbg & 15) == 2) {                                  // debug: h0 chunk 0 of tile 0 as [2PC][HPXP]
+    if ((a.dbg & 15) == 2) {                           // debug: h0 chunk 0 of tile 0 as [2PC][HPXP]
       if (blockIdx.x == 0)
-        for (int e = t; e < 2 * PC * K::HPXP; e += 512) a.out[e] = H0[(e / K::HPXP) * K::PLANE + e % K::HPXP];
+        for (int e = t; e < 2 * PC * K::HPXP; e += NT) a.out[e] = H0[(e / K::HPXP) * K::PLANE + e % K::HPXP];
       return;
     }
 
     // ------------------------------------------------------------ depthwise 3x3 + GELU gate, VALU; weights for the next GEMMs in flight
     {
-      u32x4 wr1[W1N], wr2[W2N];
+      u32x4 wr1[W1N], wr2[W2N], wrd = {0u, 0u, 0u, 0u};
       const bool more = c + 1 < a.nch;
+      const float* const wdc = WD + (c & 1) * (PC * 20);
       {
+        if (more && t < WDV) wrd = reinterpret_cast<const u32x4*>(a.wdp + (int64_t)(c + 1) * PC * 20)[t];
         const u32x4* s1 = reinterpret_cast<const u32x4*>(a.w1p + (int64_t)(c + 1) * 2 * PC * K::W1S);
         const u32x4* s2 = reinterpret_cast<const u32x4*>(a.w2p + (int64_t)c * C * K::W2S);
 #pragma unroll
-        for (int n = 0; n < W1N; ++n) { const int v = t + 512 * n; if (more && v < W1V) wr1[n] = s1[v]; }
+        for (int n = 0; n < W1N; ++n) { const int v = t + NT * n; if (more && v < W1V) wr1[n] = s1[v]; }
 #pragma unroll
-        for (int n = 0; n < W2N; ++n) { const int v = t + 512 * n; if (v < W2V) wr2[n] = s2[v]; }
+        for (int n = 0; n < W2N; ++n) { const int v = t + NT * n; if (v < W2V) wr2[n] = s2[v]; }
       }
-      const int cg = lane & 7;
+      const int cg = lane % K::CG, rl = (lane / K::CG) % K::ROWS, psel = lane / (K::CG * K::ROWS);
 #pragma unroll 1
-      for (int s = 0; s < K::PPW; ++s) {
-        const int p = wv * K::PPW + s;
-        const float* wp = a.wdp + ((int64_t)c * PC + p) * 20;
+      for (int s = 0; s < ((a.dbg & 64) ? 0 : K::PPW / K::NPAIR); ++s) {
+        const int p = wv * K::PPW + s * K::NPAIR + psel;
+        const float* wp = wdc + p * 20;
         f32x2 w[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-          w[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i])));
-          w[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i + 1])));
+          if constexpr (K::NPAIR == 1) {               // one pair per wave: the taps live in scalar registers
+            w[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i])));
+            w[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i + 1])));
+          } else {
+            w[i] = *reinterpret_cast<const f32x2*>(wp + 2 * i);
+          }
         }
         const bf16* h1 = &H0[p * K::PLANE];
         const bf16* h2 = &H0[(PC + p) * K::PLANE];
-        const int eoff = K::BODY + (cg == 7 ? K::HR : 0);
+        const int eoff = K::BODY + (cg == K::CG - 1 ? K::HR : 0);
 #pragma unroll
-        for (int rp = 0; rp < K::RP; ++rp) {
-          const int row = rp * 8 + (lane >> 3);
+        for (int rp = 0; rp < K::PASSES; ++rp) {
+          const int row = rp * K::ROWS + rl;
           f32x2 o[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = w[9];
 #pragma unroll
           for (int dr = 0; dr < 3; ++dr) {
             const int rin = row + dr;
-            const u32x4 r1 = *reinterpret_cast<const u32x4*>(h1 + rin * 64 + 8 * cg);
-            const u32x4 r2 = *reinterpret_cast<const u32x4*>(h2 + rin * 64 + 8 * cg);
+            const u32x4 r1 = *reinterpret_cast<const u32x4*>(h1 + rin * TW + 8 * cg);
+            const u32x4 r2 = *reinterpret_cast<const u32x4*>(h2 + rin * TW + 8 * cg);
             const u16 e1 = reinterpret_cast<const u16*>(h1)[eoff + rin];
             const u16 e2 = reinterpret_cast<const u16*>(h2)[eoff + rin];
             f32x2 v[10];
@@ -395,7 +435,7 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
             lft[0] = from_prev_lane(v[8][0]); lft[1] = from_prev_lane(v[8][1]);
             rgt[0] = from_next_lane(v[1][0]); rgt[1] = from_next_lane(v[1][1]);
             v[0] = cg == 0 ? edge : lft;
-            v[9] = cg == 7 ? edge : rgt;
+            v[9] = cg == K::CG - 1 ? edge : rgt;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -404,83 +444,92 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
           float gg[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) gg[j] = gelu_erf(o[j][0]) * o[j][1];
-          Vec<bf16, 8>::st(&G[p * K::GS + row * 64 + 8 * cg], gg);
+          Vec<bf16, 8>::st(&G[p * K::GS + row * TW + 8 * cg], gg);
         }
       }
 #pragma unroll
-      for (int n = 0; n < W1N; ++n) { const int v = t + 512 * n; if (more && v < W1V) reinterpret_cast<u32x4*>(W1)[v] = wr1[n]; }
+      for (int n = 0; n < W1N; ++n) { const int v = t + NT * n; if (more && v < W1V) reinterpret_cast<u32x4*>(W1)[v] = wr1[n]; }
 #pragma unroll
-      for (int n = 0; n < W2N; ++n) { const int v = t + 512 * n; if (v < W2V) reinterpret_cast<u32x4*>(W2)[v] = wr2[n]; }
+      for (int n = 0; n < W2N; ++n) { const int v = t + NT * n; if (v < W2V) reinterpret_cast<u32x4*>(W2)[v] = wr2[n]; }
+      if (more && t < WDV) reinterpret_cast<u32x4*>(WD + ((c + 1) & 1) * (PC * 20))[t] = wrd;
     }
     __syncthreads();
-    if ((a.dbg & 15) == 3) {                                  // debug: gate output chunk 0 of tile 0 as [PC][TH*64]
+    if ((a.dbg & 15) == 3) {                           // debug: gate output chunk 0 of tile 0 as [PC][TH*TW]
       if (blockIdx.x == 0)
-        for (int e = t; e < PC * TH * 64; e += 512) a.out[e] = G[(e / (TH * 64)) * K::GS + e % (TH * 64)];
+        for (int e = t; e < PC * TH * TW; e += NT) a.out[e] = G[(e / (TH * TW)) * K::GS + e % (TH * TW)];
       return;
     }
 
     // ------------------------------------------------------------ GEMM2: acc[tile rows of this wave][C] += g^T . W_out[chunk]^T
-    {
-      s16x8 bo8[K::CT];
-      s16x4 bo4[K::CT];
+    if (!(a.dbg & 128)) {
+      s16x8 bo[K::CT];
 #pragma unroll
       for (int ct = 0; ct < K::CT; ++ct) {
         const bf16* wr = &W2[(ct * 16 + li) * K::W2S + 4 * g];
-        if (PC == 32) bo8[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), *reinterpret_cast<const s16x4*>(wr + 16));
-        else bo4[ct] = *reinterpret_cast<const s16x4*>(wr);
+        if (PC == 32) bo[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), *reinterpret_cast<const s16x4*>(wr + 16));
+        else bo[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), (s16x4){0, 0, 0, 0});   // 16 pairs: zero-padded k
       }
 #pragma unroll
-      for (int j = 0; j < K::RP; ++j) {
-        const bf16* gp = &G[(4 * g + qq) * K::GS + (wv + 8 * j) * 64 + 4 * pp];
-        s16x4 lo[4], hi[4];
+      for (int j = 0; j < K::RPW; ++j) {
+        const bf16* gp = &G[(4 * g + qq) * K::GS + (wv + NW * j) * TW + 4 * pp];
+        s16x4 lo[K::QT], hi[K::QT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < K::QT; ++q) {
           lo[q] = tr_b16(gp + 16 * q);
-          hi[q] = PC == 32 ? tr_b16(gp + 16 * K::GS + 16 * q) : lo[q];
+          hi[q] = (s16x4){0, 0, 0, 0};
+          if (PC == 32) hi[q] = tr_b16(gp + 16 * K::GS + 16 * q);
         }
-        lds_wait(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+        if constexpr (K::QT == 4) lds_wait(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+        else lds_wait(lo[0], lo[1], hi[0], hi[1]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < K::QT; ++q)
 #pragma unroll
-          for (int ct = 0; ct < K::CT; ++ct) {
-            if (PC == 32) acc[j][q][ct] = mfma32(cat8(lo[q], hi[q]), bo8[ct], acc[j][q][ct]);
-            else acc[j][q][ct] = mfma32(cat8(lo[q], (s16x4){0, 0, 0, 0}), cat8(bo4[ct], (s16x4){0, 0, 0, 0}), acc[j][q][ct]);
-          }
+          for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = mfma32(cat8(lo[q], hi[q]), bo[ct], acc[j][q][ct]);
       }
     }
   }
 
-  // ---------------------------------------------------------------- epilogue: + bias + residual y, whole 128-byte rows
+  // ---------------------------------------------------------------- epilogue: + bias + residual y, whole row segments
   // (wave-private fp32 slab inside the h0 region: nobody reads h0 after the last barrier)
   {
     float* slab = reinterpret_cast<float*>(fg_lds) + wv * 16 * K::SLAB_OS;
-    const int e_row = lane >> 3, e_col = (lane & 7) * 8;
+    const int e_row = lane / K::LPR, e_col = (lane % K::LPR) * 8;
+    u32x4 rr[K::RPW][K::CT][K::ITS];
+    float bv[K::CT][K::ITS];
 #pragma unroll
-    for (int j = 0; j < K::RP; ++j) {
-      const int64_t pix = (int64_t)(y0 + wv + 8 * j) * a.W + x0 + e_col;
+    for (int ct = 0; ct < K::CT; ++ct)
+#pragma unroll
+      for (int it = 0; it < K::ITS; ++it) bv[ct][it] = a.b2[ct * 16 + it * K::RPI + e_row];
+#pragma unroll
+    for (int j = 0; j < K::RPW; ++j) {
+      const int64_t pix = (int64_t)(y0 + wv + NW * j) * a.W + x0 + e_col;
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct)
+#pragma unroll
+        for (int it = 0; it < K::ITS; ++it)
+          rr[j][ct][it] = *reinterpret_cast<const u32x4*>(yb + (int64_t)(ct * 16 + it * K::RPI + e_row) * HW + pix);
+    }
+#pragma unroll
+    for (int j = 0; j < K::RPW; ++j) {
+      const int64_t pix = (int64_t)(y0 + wv + NW * j) * a.W + x0 + e_col;
 #pragma unroll
       for (int ct = 0; ct < K::CT; ++ct) {
-        u32x4 rr[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-          rr[it] = *reinterpret_cast<const u32x4*>(yb + (int64_t)(ct * 16 + it * 8 + e_row) * HW + pix);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < K::QT; ++q) {
           float v[4] = {acc[j][q][ct][0], acc[j][q][ct][1], acc[j][q][ct][2], acc[j][q][ct][3]};
           Vec<float, 4>::st(&slab[li * K::SLAB_OS + 16 * q + 4 * g], v);
         }
         wave_sync();
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int m = ct * 16 + it * 8 + e_row;
+        for (int it = 0; it < K::ITS; ++it) {
+          const int m = ct * 16 + it * K::RPI + e_row;
           float v[8];
-          Vec<float, 4>::ld(&slab[(it * 8 + e_row) * K::SLAB_OS + e_col], v);
-          Vec<float, 4>::ld(&slab[(it * 8 + e_row) * K::SLAB_OS + e_col + 4], v + 4);
-          const float bv = a.b2[m];
+          Vec<float, 4>::ld(&slab[(it * K::RPI + e_row) * K::SLAB_OS + e_col], v);
+          Vec<float, 4>::ld(&slab[(it * K::RPI + e_row) * K::SLAB_OS + e_col + 4], v + 4);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            v[2 * k] += bv + bf_lo(rr[it][k]);
-            v[2 * k + 1] += bv + bf_hi(rr[it][k]);
+            v[2 * k] += bv[ct][it] + bf_lo(rr[j][ct][it][k]);
+            v[2 * k + 1] += bv[ct][it] + bf_hi(rr[j][ct][it][k]);
           }
           Vec<bf16, 8>::st(a.out + ((int64_t)b * C + m) * HW + pix, v);
         }
@@ -491,19 +540,28 @@ __global__ __launch_bounds__(512) void fg_fwd_kernel(FgArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// Tile configurations.  Default: 4-wave workgroups on 32-pixel-wide tiles, two workgroups per CU - the two run out of
+// phase, so one's HBM prologue / epilogue and MFMA phases overlap the other's VALU-bound conv phase (a single 8-wave
+// workgroup per CU on 64-wide tiles serialises them: 1.5 ms instead of ... at C = 96, 256^2, bs 32).
+// A/B switch (read per call): MI_FG_CFG=w64 selects the 8-wave 64-wide tiles; th8 / pc16 / pc32 override rows / pairs per chunk.
+struct FgSel { int th, tw, pc, nw; };
+static FgSel fg_select(int C, int H) {
+  const char* e = getenv("MI_FG_CFG");
+  FgSel f;
+  if (e && strstr(e, "w64")) {
+    f.tw = 64; f.nw = 8;
+    f.th = (C == 48 && !strstr(e, "th8") && H % 16 == 0) ? 16 : 8;
+    f.pc = (C == 48 && f.th == 16) ? 16 : 32;
+    if (strstr(e, "pc16")) f.pc = 16;
+    return f;
+  }
+  f.tw = 32; f.nw = 4;
+  f.th = (C == 48 && !(e && strstr(e, "th8")) && H % 16 == 0) ? 16 : 8;
+  f.pc = 16;
+  if (e && strstr(e, "pc32") && f.th == 8) f.pc = 32;
+  return f;
+}
 enum FgKind { FG_NONE = 0, FG_C48, FG_C96 };
-// A/B switch (read per call): MI_FG_CFG=th8 runs C = 48 on 8-row tiles, MI_FG_CFG=pc16 / pc32 overrides the pairs per chunk
-static int fg_cfg_th(int C, int H) {
-  const char* e = getenv("MI_FG_CFG");
-  if (C == 48 && !(e && strstr(e, "th8")) && H % 16 == 0) return 16;
-  return 8;
-}
-static int fg_cfg_pc(int C, int th) {
-  const char* e = getenv("MI_FG_CFG");
-  if (e && strstr(e, "pc16")) return 16;
-  if (e && strstr(e, "pc32") && th == 8) return 32;
-  return (C == 48 && th == 16) ? 16 : 32;
-}
 static FgKind fg_kind(const mi_gdfn_fused_shape* s) {
   if (!s || s->B <= 0 || s->hidden <= 0) return FG_NONE;
   if (s->W % 64 != 0 || s->H % 8 != 0) return FG_NONE;
@@ -512,25 +570,26 @@ static FgKind fg_kind(const mi_gdfn_fused_shape* s) {
   return FG_NONE;
 }
 
-template <int C, int TH, int PC>
+template <int C, int TH, int TW, int PC, int NW>
 static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const void* pack, const void* y, void* out,
                      float* mean, float* rstd, hipStream_t st) {
-  using K = FgCfg<C, TH, PC>;
+  using K = FgCfg<C, TH, TW, PC, NW>;
   FgArgs a;
   const unsigned char* pk = (const unsigned char*)pack;
   a.y = (const bf16*)y; a.out = (bf16*)out; a.mean = mean; a.rstd = rstd;
-  a.w1p = (const bf16*)(pk + l.w1p); a.w2p = (const bf16*)(pk + l.w2p); a.b1p = (const float*)(pk + l.b1p);
+  a.w1p = (const bf16*)(pk + l.w1p); a.w2p = (const bf16*)(pk + l.w2p);
   a.wdp = (const float*)(pk + l.wdp); a.b2 = (const float*)(pk + l.b2);
   a.B = s->B; a.H = s->H; a.W = s->W; a.nch = l.nch; a.with_bias = s->ln_with_bias;
-  a.tiles_x = s->W / 64; a.tiles_y = s->H / TH;
+  a.tiles_x = s->W / TW; a.tiles_y = s->H / TH;
   { const char* e = getenv("MI_FG_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const int64_t tiles = (int64_t)s->B * a.tiles_x * a.tiles_y;
   MI_CHECK_ARG(tiles < (1ll << 31), "gdfn_fused: grid too large");
-  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, PC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  a.xcd_pairs = (TW == 32 && tiles % 16 == 0 && !getenv("MI_FG_NOXCD")) ? 1 : 0;
+  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES));
   const double N = (double)s->H * s->W * s->B, h = s->hidden;
   ProfScope ps(st, K_GDFN_FUSED_FWD, 2.0 * C * N * 2.0, 2.0 * N * (3.0 * C * h) + 2.0 * N * 9.0 * 2.0 * h);
-  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, PC>), dim3((unsigned)tiles), dim3(512), K::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, TW, PC, NW>), dim3((unsigned)tiles), dim3(64 * NW), K::LDS_BYTES, st, a);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -555,13 +614,13 @@ extern "C" int mi_gdfn_fused_pack(const mi_gdfn_fused_shape* s, const float* ln_
   MI_CHECK_ARG(ln_w && p && p->in_w && p->dw_w && p->out_w && pack, "gdfn_fused_pack: null pointer");
   MI_CHECK_ARG((s->ln_with_bias != 0) == (ln_b != nullptr), "gdfn_fused_pack: ln_with_bias does not match ln_b");
   MI_CHECK_ARG(aligned16(pack), "gdfn_fused_pack: pack buffer must be 16-byte aligned");
-  const int PC = fg_cfg_pc(s->C, fg_cfg_th(s->C, s->H));
+  const int PC = fg_select(s->C, s->H).pc;
   const FgPackLayout l = fg_pack_layout(s->C, s->hidden, PC);
   unsigned char* pk = (unsigned char*)pack;
   FgPackArgs a;
   a.ln_w = ln_w; a.ln_b = ln_b; a.in_w = p->in_w; a.in_b = p->in_b; a.dw_w = p->dw_w; a.dw_b = p->dw_b;
   a.out_w = p->out_w; a.out_b = p->out_b;
-  a.w1p = (bf16*)(pk + l.w1p); a.w2p = (bf16*)(pk + l.w2p); a.b1p = (float*)(pk + l.b1p); a.wdp = (float*)(pk + l.wdp);
+  a.w1p = (bf16*)(pk + l.w1p); a.w2p = (bf16*)(pk + l.w2p); a.wdp = (float*)(pk + l.wdp);
   a.b2 = (float*)(pk + l.b2);
   a.C = s->C; a.h = s->hidden; a.PC = PC; a.nch = l.nch;
   hipStream_t st = (hipStream_t)stream;
@@ -578,14 +637,23 @@ extern "C" int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack,
   MI_CHECK_ARG(pack && y && out, "gdfn_fused_fwd: null pointer");
   MI_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "gdfn_fused_fwd: mean and rstd go together");
   MI_CHECK_ARG(aligned16(pack) && aligned16(y) && aligned16(out), "gdfn_fused_fwd: pointers must be 16-byte aligned");
-  const int th = fg_cfg_th(s->C, s->H), pc = fg_cfg_pc(s->C, th);
-  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, pc);
+  const FgSel f = fg_select(s->C, s->H);
+  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, f.pc);
   hipStream_t st = (hipStream_t)stream;
-  if (k == FG_C48) {
-    if (th == 16) return fg_launch<48, 16, 16>(s, l, pack, y, out, mean, rstd, st);
-    if (pc == 16) return fg_launch<48, 8, 16>(s, l, pack, y, out, mean, rstd, st);
-    return fg_launch<48, 8, 32>(s, l, pack, y, out, mean, rstd, st);
-  }
-  if (pc == 16) return fg_launch<96, 8, 16>(s, l, pack, y, out, mean, rstd, st);
-  return fg_launch<96, 8, 32>(s, l, pack, y, out, mean, rstd, st);
+#define FG_CASE(CC, TH, TW, PC, NW) \
+  if (s->C == CC && f.th == TH && f.tw == TW && f.pc == PC && f.nw == NW) \
+    return fg_launch<CC, TH, TW, PC, NW>(s, l, pack, y, out, mean, rstd, st)
+  FG_CASE(48, 16, 32, 16, 4);
+  FG_CASE(48, 8, 32, 16, 4);
+  FG_CASE(48, 8, 32, 32, 4);
+  FG_CASE(96, 8, 32, 16, 4);
+  FG_CASE(96, 8, 32, 32, 4);
+  FG_CASE(48, 16, 64, 16, 8);
+  FG_CASE(48, 8, 64, 32, 8);
+  FG_CASE(48, 8, 64, 16, 8);
+  FG_CASE(96, 8, 64, 32, 8);
+  FG_CASE(96, 8, 64, 16, 8);
+#undef FG_CASE
+  set_error("gdfn_fused_fwd: no kernel for C=%d th=%d tw=%d pc=%d", s->C, f.th, f.tw, f.pc);
+  return MI_ERR_ARG;
 }

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch.distributions.normal import Normal
 
 from . import ops
-from .restormer import (Attention, FeedForward, LayerNorm, _BlockFn, _Conv1x1Fn, _CrossAttentionFn,  # noqa: F401
+from .restormer import (Attention, FeedForward, LayerNorm, _apply, _BlockFn, _Conv1x1Fn, _CrossAttentionFn,  # noqa: F401
                         _DwConvFn)
 
 __all__ = ["SparseDispatcher", "LayerNorm", "FeedForward", "Attention", "CrossAttention", "FFTAttention", "MySequential",
@@ -28,11 +28,11 @@ __all__ = ["SparseDispatcher", "LayerNorm", "FeedForward", "Attention", "CrossAt
 
 def _c1(x, conv: nn.Conv2d):
     """1x1 conv module applied through the native pointwise GEMM."""
-    return _Conv1x1Fn.apply(x, None, conv.weight, conv.bias)
+    return _apply(_Conv1x1Fn, x, None, conv.weight, conv.bias)
 
 
 def _dw(x, conv: nn.Conv2d):
-    return _DwConvFn.apply(x, conv.weight, conv.bias)
+    return _apply(_DwConvFn, x, conv.weight, conv.bias)
 
 
 class _GapFn(torch.autograd.Function):
@@ -138,7 +138,7 @@ class CrossAttention(nn.Module):
                 self.kv.bias, self.kv_dwconv.weight, self.kv_dwconv.bias, self.project_out.weight, self.project_out.bias)
 
     def forward(self, x, y):
-        return _CrossAttentionFn.apply(x, y, self.num_heads, *self._params())
+        return _apply(_CrossAttentionFn, x, y, self.num_heads, *self._params())
 
 
 class FFTAttention(nn.Module):
@@ -356,7 +356,7 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x):
         params = self.norms[0]._params() + self.mixer._params() + self.norms[1]._params() + self.ffn._params()
-        return _BlockFn.apply(x, self.mixer.num_heads, *params)
+        return _apply(_BlockFn, x, self.mixer.num_heads, *params)
 
 
 class DecoderBlock(nn.Module):

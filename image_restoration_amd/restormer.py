@@ -14,6 +14,7 @@ in place and reports no autograd gradient for the parameters; otherwise ordinary
 from __future__ import annotations
 
 import numbers
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -46,10 +47,24 @@ def _fresh_grads(params: Sequence[Optional[Tensor]]) -> List[Optional[Tensor]]:
 # ======================================================================================
 # autograd glue
 # ======================================================================================
+# Inside Function.forward grad mode is always off and ctx.needs_input_grad ignores torch.no_grad(), so the caller's grad
+# mode is recorded right before .apply(): under no_grad nothing is saved for backward (no blobs, no LN statistics).
+_tls = threading.local()
+
+
+def _apply(fn, *args):
+    _tls.grad = torch.is_grad_enabled()
+    return fn.apply(*args)
+
+
+def _grad_mode() -> bool:
+    return getattr(_tls, "grad", True)
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        need = any(ctx.needs_input_grad)
+        need = _grad_mode() and any(ctx.needs_input_grad)
         y, mean, rstd = ops.ln_fwd(x, weight, bias, bias is not None, want_stats=need)
         if need:
             ctx.save_for_backward(x, weight, mean, rstd)
@@ -71,7 +86,7 @@ class _LayerNormFn(torch.autograd.Function):
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, heads, *params):
-        need = any(ctx.needs_input_grad)
+        need = _grad_mode() and any(ctx.needs_input_grad)
         out, saved = ops.mdta_fwd(x, None, params, heads, need)
         if need:
             ctx.heads = heads
@@ -95,7 +110,7 @@ class _AttentionFn(torch.autograd.Function):
 class _FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *params):
-        need = any(ctx.needs_input_grad)
+        need = _grad_mode() and any(ctx.needs_input_grad)
         out, saved = ops.gdfn_fwd(x, None, params, need)
         if need:
             ctx.mg = _main_grads(params)
@@ -126,7 +141,7 @@ class _BlockFn(torch.autograd.Function):
         att = params[2:9]
         n2 = params[9:11]
         ffn = params[11:17]
-        need = any(ctx.needs_input_grad)
+        need = _grad_mode() and any(ctx.needs_input_grad)
         wb = n1[1] is not None
         xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
         y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
@@ -156,10 +171,46 @@ class _BlockFn(torch.autograd.Function):
         return (dx, None) + tuple(None if acc else g for g in grads)
 
 
+def _fused_gdfn_pack(holder, like: Tensor, ln_params, ffn_params) -> Tensor:
+    """Packed weight images of the one-launch LN + GDFN kernel, cached on the module and re-packed whenever one of the
+    eight parameters was written (torch bumps ``_version`` on every in-place update, optimizer steps and
+    ``load_state_dict`` included) or replaced."""
+    ps = tuple(ln_params) + tuple(ffn_params)
+    key = tuple((p.data_ptr(), p._version) if p is not None else None for p in ps) + (like.shape[2], like.shape[3])
+    cache = getattr(holder, "_fg_pack", None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.gdfn_fused_pack(like, ln_params[0], ln_params[1], tuple(ffn_params)))
+        holder._fg_pack = cache
+    return cache[1]
+
+
+def _block_infer(block, x: Tensor, params) -> Tensor:
+    """TransformerBlock.forward under no_grad (Restormer.py:146-150): nothing is saved, and the second half of the block
+    (norm2 -> ffn -> +x) runs as ONE kernel where the fused GDFN covers the shape (bf16, C = 48 / 96, tile-aligned planes)."""
+    _gpu_block_input(x)
+    n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
+    wb = n1[1] is not None
+    xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
+    y, _ = ops.mdta_fwd(xn, x, att, block.attn.num_heads, False)
+    hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
+    if ops.gdfn_fused_ok(y, hidden, ks):
+        pack = _fused_gdfn_pack(block, y, n2, ffn)
+        out, _, _ = ops.gdfn_fused_fwd(y, pack, hidden, wb, want_stats=False)
+        return out
+    yn, _, _ = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=False)
+    out, _ = ops.gdfn_fwd(yn, y, ffn, False)
+    return out
+
+
+def _gpu_block_input(x: Tensor) -> None:
+    if not x.is_contiguous():
+        raise RuntimeError("image_restoration_amd ops need contiguous NCHW tensors")
+
+
 class _CrossAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, heads, *params):
-        need = any(ctx.needs_input_grad)
+        need = _grad_mode() and any(ctx.needs_input_grad)
         out, saved = ops.xmdta_fwd(x, y, None, params, heads, need)
         if need:
             ctx.heads = heads
@@ -318,7 +369,7 @@ class LayerNorm(nn.Module):
         return self.body.weight, getattr(self.body, "bias", None)
 
     def forward(self, x):
-        return _LayerNormFn.apply(x, *self._params())
+        return _apply(_LayerNormFn, x, *self._params())
 
 
 class FeedForward(nn.Module):
@@ -337,7 +388,7 @@ class FeedForward(nn.Module):
                 self.project_out.weight, self.project_out.bias)
 
     def forward(self, x):
-        return _FeedForwardFn.apply(x, *self._params())
+        return _apply(_FeedForwardFn, x, *self._params())
 
 
 class Attention(nn.Module):
@@ -356,7 +407,7 @@ class Attention(nn.Module):
                 self.project_out.weight, self.project_out.bias)
 
     def forward(self, x):
-        return _AttentionFn.apply(x, self.num_heads, *self._params())
+        return _apply(_AttentionFn, x, self.num_heads, *self._params())
 
 
 class TransformerBlock(nn.Module):
@@ -371,7 +422,9 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         params = self.norm1._params() + self.attn._params() + self.norm2._params() + self.ffn._params()
-        return _BlockFn.apply(x, self.attn.num_heads, *params)
+        if not torch.is_grad_enabled() and x.is_cuda:
+            return _block_infer(self, x, params)
+        return _apply(_BlockFn, x, self.attn.num_heads, *params)
 
 
 class _ThinConv3x3Fn(torch.autograd.Function):
@@ -432,7 +485,7 @@ def _conv2d(x: Tensor, conv: nn.Conv2d, residual: Optional[Tensor] = None) -> Te
     (_ThinConv3x3Fn); the C -> C/2 and C -> 2C convs of Down/Upsample are still a PyTorch-ROCm (MIOpen) op."""
     if (min(conv.weight.shape[0], conv.weight.shape[1]) <= 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and x.is_cuda and ops.glue3x3_ok(x.shape[2], x.shape[3]) and x.is_contiguous()):
-        return _ThinConv3x3Fn.apply(x, conv.weight, conv.bias, residual)
+        return _apply(_ThinConv3x3Fn, x, conv.weight, conv.bias, residual)
     y = _conv2d_torch(x, conv)
     return y if residual is None else y + residual
 
@@ -525,17 +578,17 @@ class Restormer(nn.Module):
         latent = self.latent(self.down3_4(out_enc_level3))
 
         # concat-free channel reduce: two K-panels of one 1x1 GEMM (Restormer.py:259-261)
-        inp_dec_level3 = _Conv1x1Fn.apply(self.up4_3(latent), out_enc_level3, self.reduce_chan_level3.weight,
+        inp_dec_level3 = _apply(_Conv1x1Fn, self.up4_3(latent), out_enc_level3, self.reduce_chan_level3.weight,
                                           self.reduce_chan_level3.bias)
         out_dec_level3 = self.decoder_level3(inp_dec_level3)
-        inp_dec_level2 = _Conv1x1Fn.apply(self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
+        inp_dec_level2 = _apply(_Conv1x1Fn, self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
                                           self.reduce_chan_level2.bias)
         out_dec_level2 = self.decoder_level2(inp_dec_level2)
         inp_dec_level1 = torch.cat([self.up2_1(out_dec_level2), out_enc_level1], 1)
         out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
 
         if self.dual_pixel_task:
-            out_dec_level1 = out_dec_level1 + _Conv1x1Fn.apply(inp_enc_level1, None, self.skip_conv.weight,
+            out_dec_level1 = out_dec_level1 + _apply(_Conv1x1Fn, inp_enc_level1, None, self.skip_conv.weight,
                                                                self.skip_conv.bias)
             return _conv2d(out_dec_level1, self.output)
         return _conv2d(out_dec_level1, self.output, inp_img)

@@ -25,7 +25,7 @@ ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the fla
 class FlatTrainer:
     def __init__(self, model: nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, process_group=None, overlap: bool = True, host_update=None,
-                 pack_cache: bool = True):
+                 pack_cache: bool = True, bucket_blocks: bool = True):
         self.model = model
         # host_update(trainer, scale): test hook that stands in for the fused AdamW kernel when the gradient-bucketing /
         # all-reduce bookkeeping is exercised on CPU tensors over gloo.  The product has no CPU update: without the hook,
@@ -59,15 +59,21 @@ class FlatTrainer:
                 self.offsets[id(p)] = (o, n)
         self.params = params
         self.total = total
-        # stages = top-level children that own parameters; their flat ranges are contiguous by construction
+        # reduction units ("stages"): the top-level children that own parameters, with nn.Sequential stages split into
+        # their blocks (a 256^2 stage's four blocks take ~10 ms of backward each: per-block buckets let the first reduce
+        # start that much earlier and leave only the patch embedding behind the last one); flat ranges are contiguous
+        # by construction (parameters() order = registration order)
         self.stages: List[Tuple[str, nn.Module, int, int]] = []
         for name, child in model.named_children():
-            ps = [p for p in child.parameters() if p.requires_grad]
-            if not ps:
-                continue
-            lo = min(self.offsets[id(p)][0] for p in ps)
-            hi = max(self.offsets[id(p)][0] + (self.offsets[id(p)][1] + ALIGN - 1) // ALIGN * ALIGN for p in ps)
-            self.stages.append((name, child, lo, hi))
+            units = [(f"{name}.{i}", sub) for i, sub in enumerate(child)] if (bucket_blocks and isinstance(child, nn.Sequential)
+                                                                             and len(child) > 1) else [(name, child)]
+            for uname, unit in units:
+                ps = [p for p in unit.parameters() if p.requires_grad]
+                if not ps:
+                    continue
+                lo = min(self.offsets[id(p)][0] for p in ps)
+                hi = max(self.offsets[id(p)][0] + (self.offsets[id(p)][1] + ALIGN - 1) // ALIGN * ALIGN for p in ps)
+                self.stages.append((uname, unit, lo, hi))
         self.overlap = overlap and self.world > 1
         self._exec_order: List[int] = []
         self._reduced: set = set()
@@ -81,8 +87,74 @@ class FlatTrainer:
         # copies of all 1x1 weights across calls and refresh them once per optimizer step (mi_pw_cache_*): 4 bytes of
         # cache per parameter covers both orientations of every matrix in either activation dtype, plus tile padding.
         self._pack_cache = bool(pack_cache) and dev.type == "cuda"
+        self._sync = True            # False inside no_sync(): micro-batches accumulate locally, nothing is reduced
+        self._seen_fwd: set = set()
+        self._ready: set = set()
+        self._next = len(self.stages) - 1
+        self._bwd_started = False
         if self._pack_cache:
             ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat_p)
+            # Anything that writes the parameters other than optimizer_step (load_state_dict to resume or to evaluate a
+            # checkpoint, an EMA copy-back, a manual re-init) must not leave the GEMMs on stale packed images: torch bumps
+            # the flat buffer's version counter on every in-place write through a view, the fused AdamW kernel (a raw
+            # pointer write) does not, so a version change seen at the next forward means "somebody else wrote": re-pack.
+            self._p_version = self.flat_p._version
+            model.register_load_state_dict_post_hook(lambda *_: self.weights_changed())
+            model.register_forward_pre_hook(lambda *_: self._check_weights())
+
+    # ------------------------------------------------------------------ packed-weight cache safety
+    def weights_changed(self) -> None:
+        """Tell the trainer the parameters were written outside optimizer_step (called automatically after
+        load_state_dict and whenever the flat buffer's version counter moved)."""
+        if self._pack_cache:
+            ops.pw_cache_refresh()
+            self._p_version = self.flat_p._version
+
+    def _check_weights(self) -> None:
+        if self._pack_cache and self.flat_p._version != self._p_version:
+            self.weights_changed()
+
+    def close(self) -> None:
+        """Detach the library's packed-weight cache from this trainer's buffers (the cache is process-global)."""
+        if self._pack_cache:
+            ops.pw_cache_enable(0, self.flat_p.device, None)
+            self._pack_cache = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ checkpointing (optimizer state; the model's own
+    # state_dict carries the parameters: Lightning's checkpoint holds both, MoCE-IR-main/src/train.py:107-116,137-148)
+    def state_dict(self) -> dict:
+        return {"exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone(), "step": self.step_count, "lr": self.lr,
+                "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "numel": int(self.total)}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if int(sd["numel"]) != int(self.total):
+            raise ValueError(f"optimizer state is for {sd['numel']} flat elements, this trainer has {self.total}")
+        self.flat_m.copy_(sd["exp_avg"])
+        self.flat_v.copy_(sd["exp_avg_sq"])
+        self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        self.betas, self.eps, self.wd = tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+        self.weights_changed()
+
+    def no_sync(self):
+        """Context manager for gradient accumulation (Lightning's accumulate_grad_batches, MoCE-IR-main/src/train.py:133):
+        backward passes inside it only accumulate into the local flat gradient; run the LAST micro-batch outside it (or
+        just call reduce_gradients afterwards) to all-reduce everything once."""
+        trainer = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                trainer._sync = False
+
+            def __exit__(self_inner, *exc):
+                trainer._sync = True
+                return False
+        return _NoSync()
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self) -> None:
@@ -90,6 +162,10 @@ class FlatTrainer:
         self._exec_order.clear()
         self._reduced.clear()
         self._works.clear()
+        self._seen_fwd.clear()
+        self._ready.clear()
+        self._next = len(self.stages) - 1
+        self._bwd_started = False
 
     def _fold_autograd_grads(self, module: nn.Module) -> None:
         """Glue layers that still run as PyTorch ops deliver .grad through autograd: add it into main_grad."""
@@ -102,16 +178,39 @@ class FlatTrainer:
         def hook(module, inputs, output):
             if not torch.is_grad_enabled() or not isinstance(output, torch.Tensor) or not output.requires_grad:
                 return
+            if not self._sync:
+                return               # accumulating: no per-stage reduction for this micro-batch
+            if idx in self._seen_fwd:
+                # a second forward before zero_grad() would add into a bucket that may already have been reduced
+                raise RuntimeError("FlatTrainer: stage ran twice between zero_grad() calls with overlapped reduction on; "
+                                   "wrap all but the last micro-batch in trainer.no_sync()")
+            self._seen_fwd.add(idx)
             self._exec_order.append(idx)
             pos = len(self._exec_order) - 1
 
             def on_grad(_grad):
-                # grad w.r.t. this stage's output is complete => every stage executed after it has finished backward
+                # grad w.r.t. this stage's output is complete => every stage executed after it has finished backward.
+                # (Holds for the chain-shaped top level of Restormer / MoCE-IR / AdaIR, where a later stage consumes an
+                # earlier one's output; skip connections only ADD consumers that ran later still.)
+                if not self._bwd_started:
+                    # stages that did not run this step (an expert nobody routed to) have nothing more to wait for
+                    self._bwd_started = True
+                    for i in range(len(self.stages)):
+                        if i not in self._seen_fwd:
+                            self._mark_ready(i)
                 for later in self._exec_order[pos + 1:]:
-                    self._launch_reduce(later)
+                    self._mark_ready(later)
                 return None
             output.register_hook(on_grad)
         return hook
+
+    def _mark_ready(self, idx: int) -> None:
+        """Collectives must be issued in ONE order on every rank, whatever order the stages finished in (ranks may route
+        to different experts): launch strictly by descending stage index, each as soon as it and all later ones are ready."""
+        self._ready.add(idx)
+        while self._next >= 0 and self._next in self._ready:
+            self._launch_reduce(self._next)
+            self._next -= 1
 
     def _launch_reduce(self, idx: int) -> None:
         if idx in self._reduced or self.world == 1:
@@ -132,8 +231,8 @@ class FlatTrainer:
         if self.world == 1:
             self._fold_autograd_grads(self.model)
             return
-        for idx in range(len(self.stages)):
-            self._launch_reduce(idx)
+        for idx in range(len(self.stages) - 1, -1, -1):
+            self._mark_ready(idx)
         for w in self._works:
             w.wait()
         if self._comm_stream is not None:
@@ -156,6 +255,7 @@ class FlatTrainer:
                            self.eps, self.wd, scale, self.dev_scalars if use_dev_scalars else None)
             if self._pack_cache:
                 ops.pw_cache_refresh()   # the weights just changed: re-pack every 1x1 weight image in one launch
+                self._p_version = self.flat_p._version
         elif self._host_update is not None:
             self._host_update(self, scale)
         else:

@@ -89,3 +89,56 @@ def test_gdfn_fused_rejects_uncovered_shapes():
     assert not ops.gdfn_fused_ok(x, 510)
     x = torch.zeros((1, 48, 16, 64), dtype=torch.float32, device=DEV)       # fp32 stays on the exact chain
     assert not ops.gdfn_fused_ok(x, 127)
+
+
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 32, 64)), (96, 2, (1, 96, 16, 128))])
+def test_block_inference_path_uses_fused_gdfn_and_matches_training_forward(c, heads, shape):
+    """TransformerBlock under no_grad (fused norm2+ffn kernel, nothing saved) vs the autograd path and the fp64 oracle;
+    the packed weights follow in-place parameter updates (version check)."""
+    m = M()
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=11 + c)
+    blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+    blk.load_state_dict(sd)
+    x = seeded_input(shape, 9000 + c).to(DEV).to(torch.bfloat16)
+    ref = R.transformer_block(x.float().cpu().double(), {k: v.double() for k, v in sd.items()}, heads, "WithBias")
+    y_train = blk(x)
+    with torch.no_grad():
+        y_inf = blk(x)
+    assert getattr(blk, "_fg_pack", None) is not None, "the no_grad path did not take the fused GDFN kernel"
+    assert rel(y_inf, ref) < 2e-2 and rel(y_train, ref) < 2e-2
+    assert rel(y_inf, y_train.float()) < 2e-2
+    # in-place weight update -> the cached pack must be rebuilt
+    with torch.no_grad():
+        blk.ffn.project_out.weight.mul_(0.5)
+        y2 = blk(x)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["ffn.project_out.weight"] = sd2["ffn.project_out.weight"] * 0.5
+    ref2 = R.transformer_block(x.float().cpu().double(), {k: v.double() for k, v in sd2.items()}, heads, "WithBias")
+    assert rel(y2, ref2) < 2e-2
+
+
+def test_trainer_pack_cache_follows_load_state_dict():
+    """step -> load_state_dict -> forward must not run the 1x1 GEMMs on stale packed weights."""
+    m = M()
+    from image_restoration_amd.trainer import FlatTrainer
+    torch.manual_seed(0)
+    net = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    tr = FlatTrainer(net, lr=1e-2)
+    x = seeded_input((1, 48, 16, 16), 77).to(DEV).to(torch.bfloat16)
+    try:
+        for _ in range(2):
+            tr.zero_grad()
+            net(x).float().abs().mean().backward()
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        y_after_steps = net(x).detach().float()
+        net.load_state_dict(sd0)                        # back to the initial weights, written in place into the flat buffer
+        y_loaded = net(x).detach().float()
+    finally:
+        tr.close()
+    fresh = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
+    fresh.load_state_dict(sd0)
+    y_ref = fresh(x).detach().float()
+    assert rel(y_loaded, y_ref) < 1e-6, "forward after load_state_dict used stale packed weights"
+    assert rel(y_after_steps, y_ref) > 1e-4            # the steps really changed the weights

@@ -59,7 +59,8 @@ def _worker(rank, world, port, overlap, ret):
         torch.manual_seed(0)
         model = TinyNet()
         tr = FlatTrainer(model, lr=1e-2, overlap=overlap, host_update=_host_adamw)
-        assert tr.world == world and len(tr.stages) == 4
+        # embed, enc.0, enc.2, dec.0, out: nn.Sequential stages are bucketed per block
+        assert tr.world == world and [n for n, *_ in tr.stages] == ["embed", "enc.0", "enc.2", "dec.0", "out"]
         g = torch.Generator().manual_seed(1)
         x = torch.randn(4, 3, 8, 8, generator=g)
         y = torch.randn(4, 3, 8, 8, generator=g)
@@ -98,6 +99,88 @@ def test_two_rank_training_matches_single_process(overlap):
     # flat ranges of the stages are disjoint and ordered by registration
     spans = sorted((lo, hi) for _, lo, hi in ret["stages"])
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+class TinyMoE(nn.Module):
+    """Two 'experts' of which a rank may route to only one (MoCE top-1 routing leaves experts grad-less in a step; the
+    reference runs DDP with find_unused_parameters=True, MoCE-IR-main/src/train.py:131)."""
+
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Conv2d(3, 4, 1)
+        self.e0 = nn.Conv2d(4, 4, 1)
+        self.e1 = nn.Conv2d(4, 4, 1)
+        self.out = nn.Conv2d(4, 3, 1)
+
+    def forward(self, x, which):
+        h = self.embed(x)
+        h = self.e0(h) if which == 0 else self.e1(h)
+        return self.out(h)
+
+
+def _worker_moe(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_restoration_amd.trainer import FlatTrainer
+        torch.manual_seed(0)
+        model = TinyMoE()
+        tr = FlatTrainer(model, lr=1e-2, overlap=True, host_update=_host_adamw)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 3, 4, 4, generator=g)
+        y = torch.randn(4, 3, 4, 4, generator=g)
+        # rank r routes its half batch to expert r: each expert's bucket is all zeros on the other rank
+        # two micro-batches per step: the first one accumulates locally inside no_sync()
+        for _ in range(2):
+            tr.zero_grad()
+            with tr.no_sync():
+                ((model(x[rank * 2:rank * 2 + 1], rank) - y[rank * 2:rank * 2 + 1]).abs().mean() * 0.5).backward()
+            ((model(x[rank * 2 + 1:rank * 2 + 2], rank) - y[rank * 2 + 1:rank * 2 + 2]).abs().mean() * 0.5).backward()
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        sd = tr.state_dict()
+        tr2_m = TinyMoE()
+        tr2 = FlatTrainer(tr2_m, lr=5e-2, overlap=False, host_update=_host_adamw)
+        tr2_m.load_state_dict(model.state_dict())
+        tr2.load_state_dict(sd)
+        assert tr2.step_count == 2 and tr2.lr == 1e-2 and torch.equal(tr2.flat_m, tr.flat_m)
+        # a second forward without no_sync() must be refused instead of silently corrupting a reduced bucket
+        tr.zero_grad()
+        model(x[:1], rank).sum().backward()
+        try:
+            model(x[:1], rank)
+            refused = False
+        except RuntimeError as e:
+            refused = "no_sync" in str(e)
+        if rank == 0:
+            ret["params"] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            ret["refused"] = refused
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unrouted_expert_zero_bucket_and_accumulation():
+    """MoCE under data parallelism: an expert a rank did not route to contributes an all-zero bucket; with no_sync()
+    micro-batches the result equals one process on the whole batch (mean over 4 samples)."""
+    torch.manual_seed(0)
+    ref = TinyMoE()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 4, 4, generator=g)
+    y = torch.randn(4, 3, 4, 4, generator=g)
+    for _ in range(2):
+        opt.zero_grad()
+        loss = 0
+        for i in range(4):
+            loss = loss + (ref(x[i:i + 1], i // 2) - y[i:i + 1]).abs().mean() / 4
+        loss.backward()
+        opt.step()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_moe, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(ret["params"][k], v, rtol=1e-5, atol=1e-6), k
+    assert ret["refused"]
 
 
 def test_cosine_warmup_schedule_closed_form():

@@ -42,6 +42,12 @@ def gdfn():
             yn, _, _ = ops.ln_fwd(y, ln_w, ln_b, True, want_stats=True)
             ops.gdfn_fwd(yn, y, params, True)
 
+        if os.environ.get("BF_ABLATE"):
+            for name, flag in (("full", 0), ("no GEMM1", 32), ("no conv", 64), ("no GEMM2", 128), ("no GEMM1/conv", 96),
+                               ("only pro/epilogue", 224), ("prologue only", 1)):
+                os.environ["MI_FG_DEBUG"] = str(flag)
+                print(f"   ablation C={C} {H}x{W}: {name:20s} {timeit(fused):8.1f} us", flush=True)
+            os.environ["MI_FG_DEBUG"] = "0"
         tf, tc = timeit(fused), timeit(chain)
         nbytes = 2.0 * B * C * H * W * 2
         flops = 2.0 * B * H * W * 3 * C * h
