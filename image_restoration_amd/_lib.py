@@ -138,6 +138,15 @@ SIGNATURES = {
     "mi_glue3x3_ok": (C.c_int, [C.c_int, C.c_int]),
     "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_moe_route_fwd": (C.c_int, [fp, fp, fp, fp, fp, fp, fp, fp, vp, fp, fp, vp, vp, vp, fp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, vp]),
+    "mi_moe_route_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, fp, vp, fp, fp, vp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, vp]),
+    "mi_patch_circconv": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_gelu_gap_fwd": (C.c_int, [vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_gelu_gap_bwd": (C.c_int, [vp, fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_ewise_fwd": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, C.c_int, C.c_int, vp]),
+    "mi_ewise_bwd": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_i64, c_i64, C.c_int, C.c_int, vp]),
     "mi_gap_fwd": (C.c_int, [vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_gap_bwd": (C.c_int, [fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),

@@ -1,29 +1,44 @@
-"""Drop-in replacements for the block classes of the reference's top-level ``moce_ir.py`` (MoCE-IR).
+"""Drop-in replacement for the reference's top-level ``moce_ir.py`` (MoCE-IR): same class names, constructor arguments,
+parameter names (``state_dict`` interchangeable) and ``forward`` signatures, rebuilt around the gfx950 kernels.
 
-Same class names, constructor arguments, parameter names and ``forward`` signatures; the heavy parts run on the gfx950
-kernels: channel LayerNorm, MDTA (``Attention``), cross-MDTA with the 7x7 depthwise kv branch (``CrossAttention``),
-GDFN (``FeedForward``), every 1x1 projection of ``DecoderBlock`` / ``ModExpert`` / ``AdapterLayer`` and the router's
-global average pool.  Still PyTorch-ROCm ops this round ("next"): the patch-FFT correlation inside
-``FFTAttention`` and the [B, E] scalar math of the router (softmax / top-k / CV^2 losses).
-
-``AdapterLayer`` keeps the reference's data flow (per-expert ragged sub-batches through ``SparseDispatcher``, one host
-sync per call as in moce_ir.py:88); the dispatcher's gather and gate-weighted scatter-add run as native row kernels.
+What runs where (reference line numbers are moce_ir.py of the upstream repository):
+  * EncoderBlock / the MDTA, cross-MDTA (7x7 depthwise kv), GDFN and LayerNorm pieces of DecoderBlock: the block kernels of
+    ``restormer.py`` (one autograd node per block).
+  * RoutingFunction (:684-800): ONE launch forward, one backward (csrc/moce.hip): both linear gates, injected noise, softmax,
+    top-k, gate scatter, the two CV^2 losses, and the dispatcher's sample -> expert tables.  The reference's nonzero / sort /
+    split bookkeeping (:82-91) is not re-enacted: the tables come out of the router launch; the only host read-back is the E
+    segment sizes (the ragged expert launches are enqueued from the host).
+  * AdapterLayer (:584-681): rows gathered by the table (native gather), every expert runs on its contiguous segment, the
+    experts' last projection (+ shortcut) is written by all experts into ONE stitched buffer (no concatenation), and the
+    gate-weighted fp32 scatter-add puts the rows back.  Train and eval share this path; for batch 1 - the only case the
+    reference's eval branch (:673-678) is meaningful for - the result is the same.
+  * FFTAttention (:373-422): ``irfft2(rfft2(q) * rfft2(k))`` per patch is a 2-D circular convolution; it is computed as one
+    (mi_patch_circconv, fp32 arithmetic like the reference's upcast) straight from the NCHW planes - no padding copy, no
+    rearrange, no FFT library call.  k and v stay channel slices of the kv tensor.
+  * FrequencyEmbedding (:1048-1075): the 3x3 high-pass depthwise conv is the native depthwise kernel, GELU + global mean one
+    kernel, the two-layer MLP on [B, dim] the native pointwise GEMM (GELU between them as the gating kernel's sibling).
+  * MoCEIR (:1080-1231): patch embedding / output conv / down / up-sampling are the native 3x3 kernels of ``restormer.py``;
+    the decoder's ``cat -> 1x1`` fusion is a two-panel GEMM (no concatenated tensor).
 """
 from __future__ import annotations
 
 import math
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.distributions.normal import Normal
 
 from . import ops
-from .restormer import (Attention, FeedForward, LayerNorm, _apply, _BlockFn, _Conv1x1Fn, _CrossAttentionFn,  # noqa: F401
-                        _DwConvFn)
+from .restormer import (Attention, Downsample, FeedForward, LayerNorm, OverlapPatchEmbed, Upsample, _apply,  # noqa: F401
+                        _BlockFn, _Conv1x1Fn, _CrossAttentionFn, _DwConvFn, _conv2d, _grad_mode, _main_grads)
 
 __all__ = ["SparseDispatcher", "LayerNorm", "FeedForward", "Attention", "CrossAttention", "FFTAttention", "MySequential",
-           "ModExpert", "AdapterLayer", "RoutingFunction", "EncoderBlock", "DecoderBlock"]
+           "ModExpert", "AdapterLayer", "RoutingFunction", "EncoderBlock", "DecoderBlock", "HighPassConv2d",
+           "FrequencyEmbedding", "EncoderResidualGroup", "DecoderResidualGroup", "OverlapPatchEmbed", "Downsample", "Upsample",
+           "MoCEIR"]
+
+Tensor = torch.Tensor
 
 
 def _c1(x, conv: nn.Conv2d):
@@ -35,6 +50,20 @@ def _dw(x, conv: nn.Conv2d):
     return _apply(_DwConvFn, x, conv.weight, conv.bias)
 
 
+def _acc_or_return(params, grads):
+    """Parameter gradients either accumulate into the trainer's flat buffer (main_grad) or are returned to autograd."""
+    mg = _main_grads(params)
+    if mg is None:
+        return list(grads)
+    for m, g in zip(mg, grads):
+        if m is not None and g is not None:
+            m.add_(g)
+    return [None] * len(grads)
+
+
+# ======================================================================================
+# autograd glue over csrc/moce.hip and csrc/dispatch.hip
+# ======================================================================================
 class _GapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -45,6 +74,36 @@ class _GapFn(torch.autograd.Function):
     def backward(ctx, dout):
         (x,) = ctx.saved_tensors
         return ops.gap_bwd(dout, x)
+
+
+class _GeluGapFn(torch.autograd.Function):
+    """mean over the plane of gelu(x): FrequencyEmbedding's activation + pooling (:1062-1064,1071-1073) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_gap_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_gap_bwd(x, dout)
+
+
+class _EwiseFn(torch.autograd.Function):
+    """op 0: a * b ; op 1: a * silu(b)."""
+
+    @staticmethod
+    def forward(ctx, a, b, op):
+        ctx.save_for_backward(a, b)
+        ctx.op = op
+        return ops.ewise_fwd(a, b, op)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        da, db = ops.ewise_bwd(a, b, dout.contiguous(), ctx.op)
+        return da, db, None
 
 
 class _RowsGatherFn(torch.autograd.Function):
@@ -63,11 +122,12 @@ class _RowsGatherFn(torch.autograd.Function):
 
 
 class _RowsCombineFn(torch.autograd.Function):
-    """combine: out[b] = sum_{i: idx[i]==b} gate[i] * src[i] in fp32 (moce_ir.py:116-124)."""
+    """combine: out[b] = sum_{i: idx[i]==b} gate[i] * src[i] in fp32 (:116-124)."""
 
     @staticmethod
     def forward(ctx, src, gates, idx, n_rows):
         src = src.contiguous()
+        ctx.gshape = None if gates is None else tuple(gates.shape)
         gates = gates.reshape(-1).float().contiguous() if gates is not None else None
         ctx.save_for_backward(src, gates, idx)
         return ops.rows_scatter_add(src, idx, gates, n_rows, out_f32=True)
@@ -77,51 +137,160 @@ class _RowsCombineFn(torch.autograd.Function):
         src, gates, idx = ctx.saved_tensors
         dout = dout.float().contiguous()
         dsrc = ops.rows_gather_scaled(dout, idx, gates, src.dtype)
-        dgates = ops.rows_dot(dout, src, idx).reshape(-1, 1) if (gates is not None and ctx.needs_input_grad[1]) else None
+        dgates = ops.rows_dot(dout, src, idx).reshape(ctx.gshape) if (gates is not None and ctx.needs_input_grad[1]) else None
         return dsrc, dgates, None, None
 
 
+class _RouteFn(torch.autograd.Function):
+    """The whole router in one launch each way.  Differentiable outputs: gates [B,E], top-k values [B,k], aux loss [1] and
+    the gate of every dispatched row [B*k]; the index tables ride along as non-differentiable outputs."""
+
+    @staticmethod
+    def forward(ctx, pooled, freq, wg, wf, noise, complexity, k, training):
+        gates, idx, vals, aux, tb = ops.moe_route_fwd(pooled, freq, wg, wf, noise, complexity, k, training)
+        ctx.save_for_backward(pooled, freq, wg, wf, noise, idx, tb.logits, tb.row_of)
+        ctx.complexity, ctx.training, ctx.tb = complexity, training, tb
+        ctx.mg = _main_grads((wg, wf))
+        for t in (idx, tb.counts, tb.offsets, tb.perm, tb.perm_expert, tb.row_of):
+            ctx.mark_non_differentiable(t)
+        return gates, idx, vals, aux, tb.perm_gate, tb.counts, tb.offsets, tb.perm, tb.perm_expert, tb.row_of
+
+    @staticmethod
+    def backward(ctx, dgates, _didx, dvals, daux, drow, *_):
+        pooled, freq, wg, wf, noise, idx, logits, row_of = ctx.saved_tensors
+        tb = ctx.tb
+        if dvals is not None:      # gradient on the top-k values = gradient on the gate of the matching dispatched row
+            extra = torch.zeros_like(tb.perm_gate).index_put_((row_of.reshape(-1).long(),), dvals.reshape(-1).float())
+            drow = extra if drow is None else drow + extra
+        dpooled, dfreq, dwg, dwf = ops.moe_route_bwd(pooled, freq, wg, wf, noise, ctx.complexity, tb, idx,
+                                                      None if dgates is None else dgates.contiguous(),
+                                                      None if drow is None else drow.contiguous(),
+                                                      None if daux is None else daux.contiguous(), ctx.training)
+        if ctx.mg is not None:
+            ctx.mg[0].add_(dwg); ctx.mg[1].add_(dwf)
+            dwg = dwf = None
+        return dpooled, dfreq, dwg, dwf, None, None, None, None
+
+
+class _FFTCoreFn(torch.autograd.Function):
+    """LayerNorm(circconv_patch(q, k)) * v with k, v the two channel halves of ``kv`` (:402-419): three launches forward, the
+    halves of d_kv written in place backward (no slice copies)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, ln_w, ln_b, patch):
+        c = q.shape[1]
+        k, v = kv[:, :c], kv[:, c:]
+        need = _grad_mode() and any(ctx.needs_input_grad)
+        cc = ops.patch_circconv(q, k, patch)
+        n, mean, rstd = ops.ln_fwd(cc, ln_w, ln_b, True, want_stats=need)
+        out = ops.ewise_fwd(n, v, 0)
+        if need:
+            ctx.save_for_backward(q, kv, cc, n, mean, rstd, ln_w)
+            ctx.patch = patch
+            ctx.mg = _main_grads((ln_w, ln_b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, cc, n, mean, rstd, ln_w = ctx.saved_tensors
+        c = q.shape[1]
+        k, v = kv[:, :c], kv[:, c:]
+        dkv = torch.empty_like(kv)
+        dn, _ = ops.ewise_bwd(n, v, dout.contiguous(), 0, db=dkv[:, c:])
+        acc = ctx.mg is not None
+        dw, db = ctx.mg if acc else (torch.empty_like(ln_w), torch.empty_like(ln_w))
+        dcc = ops.ln_bwd(dn, cc, ln_w, mean, rstd, None, True, dw, db, acc)
+        dq = ops.patch_circconv(dcc, k, ctx.patch, flip=True)
+        ops.patch_circconv(dcc, q, ctx.patch, flip=True, out=dkv[:, :c])
+        return dq, dkv, (None if acc else dw), (None if acc else db), None
+
+
+class _ExpertsOutFn(torch.autograd.Function):
+    """Last step of every expert at once (:556-558): out[rows of e] = proj[2]_e(t_e) + x[rows of e], written by the E
+    pointwise GEMMs into ONE row-stitched buffer (the reference concatenates the experts' outputs afterwards, :116)."""
+
+    @staticmethod
+    def forward(ctx, xrows, counts, *tw):
+        E = len(counts)
+        ts, ws = tw[:E], tw[E:]
+        out = torch.empty_like(xrows)
+        o = 0
+        for e, n in enumerate(counts):
+            if n:
+                ops.conv1x1(ts[e], ws[e], None, xrows[o:o + n], out=out[o:o + n])
+                o += n
+        ctx.counts = counts
+        ctx.save_for_backward(*[t for t in ts if t is not None], *ws)
+        ctx.present = [t is not None for t in ts]
+        ctx.mg = [getattr(w, "main_grad", None) for w in ws]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        E = len(ctx.counts)
+        saved = list(ctx.saved_tensors)
+        nt = sum(ctx.present)
+        it = iter(saved[:nt])
+        ts = [next(it) if pr else None for pr in ctx.present]
+        ws = saved[nt:]
+        dts, dws = [], []
+        o = 0
+        for e, n in enumerate(ctx.counts):
+            if not n:
+                dts.append(None); dws.append(None)
+                continue
+            d = dout[o:o + n]
+            dts.append(ops.conv1x1(d, ws[e], None, None, True))
+            g = ops.gram(d, ts[e], 1, True)[0].reshape(ws[e].shape)
+            if ctx.mg[e] is not None:
+                ctx.mg[e].add_(g)
+                g = None
+            dws.append(g)
+            o += n
+        return (dout, None) + tuple(dts) + tuple(dws)
+
+
+# ======================================================================================
+# modules (reference interface)
+# ======================================================================================
 class SparseDispatcher(object):
-    """Sample -> expert bookkeeping with the reference's API (moce_ir.py:71-143): ``dispatch`` gathers the rows of the
-    batch routed to each expert, ``combine`` scatters the gate-weighted expert outputs back (fp32 accumulation)."""
+    """The reference's helper API (:71-143) - ``dispatch`` / ``combine`` / ``expert_to_gates`` over gates [B, E] - kept for
+    callers that use it directly.  (AdapterLayer does not: its tables come out of the router launch.)  The index is the list of
+    (expert, sample) pairs with a non-zero gate in expert-major order - one ``nonzero`` of the transposed mask."""
 
     def __init__(self, num_experts, gates):
         self._gates = gates
         self._num_experts = num_experts
-        nz = torch.nonzero(gates)
-        sorted_experts, index_sorted_experts = nz.sort(0)
-        _, self._expert_index = sorted_experts.split(1, dim=1)
-        self._batch_index = nz[index_sorted_experts[:, 1], 0]
-        self._part_sizes = (gates > 0).sum(0).tolist()          # host sync, as moce_ir.py:88
-        gates_exp = gates[self._batch_index.flatten()]
-        self._nonzero_gates = torch.gather(gates_exp, 1, self._expert_index)
+        pairs = torch.nonzero(gates.t() > 0)                    # rows sorted by expert, then by sample
+        self._expert_index = pairs[:, :1]
+        self._batch_index = pairs[:, 1].contiguous()
+        self._part_sizes = torch.bincount(pairs[:, 0], minlength=num_experts).tolist()      # host read-back, as :88
+        self._nonzero_gates = gates[self._batch_index, pairs[:, 0]].unsqueeze(1)
 
     def dispatch(self, inp):
-        idx = self._batch_index.flatten()
         if inp.is_cuda and inp.dim() == 4 and inp.dtype in (torch.float32, torch.bfloat16):
-            inp_exp = _RowsGatherFn.apply(inp, idx)                      # native row gather (csrc/dispatch.hip)
+            rows = _RowsGatherFn.apply(inp, self._batch_index)  # native row gather (csrc/dispatch.hip)
         else:
-            inp_exp = inp[self._batch_index].squeeze(1)
-        return torch.split(inp_exp, self._part_sizes, dim=0)
+            rows = inp[self._batch_index]
+        return torch.split(rows, self._part_sizes, dim=0)
 
     def combine(self, expert_out, multiply_by_gates=True):
         stitched = torch.cat(expert_out, 0)
         if stitched.is_cuda and stitched.dim() == 4 and stitched.dtype in (torch.float32, torch.bfloat16):
-            # gate multiply + index_add into fp32 zeros in one deterministic scatter (moce_ir.py:118-124)
-            return _RowsCombineFn.apply(stitched, self._nonzero_gates if multiply_by_gates else None,
-                                        self._batch_index.flatten(), self._gates.size(0))
+            return _RowsCombineFn.apply(stitched, self._nonzero_gates if multiply_by_gates else None, self._batch_index,
+                                        self._gates.size(0))
         if multiply_by_gates:
-            stitched = stitched.mul(self._nonzero_gates.unsqueeze(-1).unsqueeze(-1))
-        zeros = torch.zeros(self._gates.size(0), expert_out[-1].size(1), expert_out[-1].size(2), expert_out[-1].size(3),
-                            requires_grad=True, device=stitched.device)
-        return zeros.index_add(0, self._batch_index, stitched.float())
+            stitched = stitched * self._nonzero_gates.view(-1, 1, 1, 1)
+        out = torch.zeros((self._gates.size(0),) + tuple(stitched.shape[1:]), dtype=torch.float32, device=stitched.device)
+        return out.index_add(0, self._batch_index, stitched.float())
 
     def expert_to_gates(self):
         return torch.split(self._nonzero_gates, self._part_sizes, dim=0)
 
 
 class CrossAttention(nn.Module):
-    """MDTA with q from ``x`` (dw 3x3) and k, v from ``y`` (dw 7x7)  (moce_ir.py:325-368)."""
+    """MDTA with q from ``x`` (dw 3x3) and k, v from ``y`` (dw 7x7)  (:325-368)."""
 
     def __init__(self, dim, num_heads, bias):
         super().__init__()
@@ -142,7 +311,7 @@ class CrossAttention(nn.Module):
 
 
 class FFTAttention(nn.Module):
-    """Expert body (moce_ir.py:373-422): per-patch circular correlation of q and k through rfft2, LayerNorm, gate by v."""
+    """Expert body (:373-422): per-patch circular convolution of q and k, LayerNorm, gate by v, 1x1 out."""
 
     def __init__(self, dim: int, **kwargs):
         super().__init__()
@@ -154,37 +323,31 @@ class FFTAttention(nn.Module):
         self.norm = LayerNorm(dim, "WithBias")
         self.proj_out = nn.Conv2d(dim, dim, kernel_size=1, padding=0)
 
-    def pad_and_rearrange(self, x):
-        b, c, h, w = x.shape
-        p = self.patch_size
-        pad_h, pad_w = (p - (h % p)) % p, (p - (w % p)) % p
-        x = F.pad(x, (0, pad_w, 0, pad_h), mode='constant', value=0)
-        hh, ww = x.shape[-2] // p, x.shape[-1] // p
-        return x.reshape(b, c, hh, p, ww, p).permute(0, 1, 2, 4, 3, 5)          # b c h w p1 p2
-
-    def rearrange_to_original(self, x, x_shape):
-        h, w = x_shape
-        b, c, hh, ww, p, _ = x.shape
-        x = x.permute(0, 1, 2, 4, 3, 5).reshape(b, c, hh * p, ww * p)
-        return x[:, :, :h, :w]
-
     def forward(self, x):
-        b, c, h, w = x.shape
         q = _dw(_c1(x, self.q), self.q_dwconv)
         kv = _dw(_c1(x, self.kv), self.kv_dwconv)
+        if self.patch_size not in (4, 8, 16, 32):
+            return self._forward_fft(x, q, kv)
+        core = _apply(_FFTCoreFn, q, kv, self.norm.body.weight, self.norm.body.bias, self.patch_size)
+        return _c1(core, self.proj_out)
+
+    def _forward_fft(self, x, q, kv):
+        """Patch sizes outside the native kernel's set (the reference configurations use 4, 8, 16, 32) go through rocFFT."""
+        b, c, h, w = x.shape
+        p = self.patch_size
         k, v = kv.chunk(2, dim=1)
-        q = self.pad_and_rearrange(q)
-        k = self.pad_and_rearrange(k)
-        out = torch.fft.rfft2(q.float()) * torch.fft.rfft2(k.float())
-        out = torch.fft.irfft2(out, s=(self.patch_size, self.patch_size))
-        out = self.rearrange_to_original(out, (h, w)).to(x.dtype).contiguous()
-        out = self.norm(out)
-        out = out * v
-        return _c1(out.contiguous(), self.proj_out)
+
+        def patches(t):
+            t = F.pad(t, (0, (p - w % p) % p, 0, (p - h % p) % p))
+            return t.reshape(b, c, t.shape[-2] // p, p, t.shape[-1] // p, p).permute(0, 1, 2, 4, 3, 5)
+        out = torch.fft.irfft2(torch.fft.rfft2(patches(q).float()) * torch.fft.rfft2(patches(k).float()), s=(p, p))
+        hh, ww = out.shape[2], out.shape[3]
+        out = out.permute(0, 1, 2, 4, 3, 5).reshape(b, c, hh * p, ww * p)[:, :, :h, :w].to(x.dtype).contiguous()
+        return _c1((self.norm(out) * v).contiguous(), self.proj_out)
 
 
 class MySequential(nn.Sequential):
-    """nn.Sequential whose layers take (x1, x2) (moce_ir.py:31-50)."""
+    """nn.Sequential whose layers take (x1, x2) (:31-50)."""
 
     def forward(self, x1, x2):
         for layer in self:
@@ -193,7 +356,7 @@ class MySequential(nn.Sequential):
 
 
 class ModExpert(nn.Module):
-    """Low-rank expert: proj[0] C->r, body, gate by silu(proj[1](shared)), proj[2] r->C, + shortcut (moce_ir.py:520-579)."""
+    """Low-rank expert: proj[0] C->r, body, gate by silu(proj[1](shared)), proj[2] r->C, + shortcut (:520-579)."""
 
     def __init__(self, dim: int, rank: int, func: nn.Module, depth: int, patch_size: int, kernel_size: int):
         super().__init__()
@@ -205,26 +368,24 @@ class ModExpert(nn.Module):
         ])
         self.body = func(rank, kernel_size=kernel_size, patch_size=patch_size)
 
-    def process(self, x, shared):
-        shortcut = x
-        x = _c1(x, self.proj[0])
-        x = self.body(x) * F.silu(_c1(shared, self.proj[1]))
-        x = _c1(x.contiguous(), self.proj[2])
-        return x + shortcut
+    def inner(self, x, shared):
+        """Everything before the last projection: body(proj[0] x) * silu(proj[1] shared)  -> [b, rank, H, W]."""
+        return _apply(_EwiseFn, self.body(_c1(x, self.proj[0])), _c1(shared, self.proj[1]), 1)
 
-    def feat_extract(self, feats, shared):
-        for _ in range(self.depth):          # the reference re-applies process to the SAME input (moce_ir.py:567-570)
-            feat = self.process(feats, shared)
-        return feat
+    def process(self, x, shared):
+        t = self.inner(x, shared)
+        return _apply(_ExpertsOutFn, x, (x.shape[0],), t, self.proj[2].weight)       # proj[2](t) + x in one GEMM epilogue
 
     def forward(self, x, shared):
         if x.shape[0] == 0:
             return x
-        return self.feat_extract(x.contiguous(), shared.contiguous())
+        # the reference re-applies `process` to the SAME input `depth` times and keeps the last result (:567-570):
+        # depth only repeats identical work, so it is applied once
+        return self.process(x.contiguous(), shared.contiguous())
 
 
 class RoutingFunction(nn.Module):
-    """Noisy top-k router (moce_ir.py:684-800).  gate = GAP -> Linear(dim, E); + Linear(freq_dim, E)(freq_emb)."""
+    """Noisy top-k router (:684-800).  gate = GAP -> Linear(dim, E); + Linear(freq_dim, E)(freq_emb)."""
 
     def __init__(self, dim, freq_dim, num_experts, k, complexity, use_complexity_bias: bool = True,
                  complexity_scale: str = "max"):
@@ -242,40 +403,39 @@ class RoutingFunction(nn.Module):
         self.num_experts = num_experts
         self.noise_std = (1.0 / num_experts) * 1.0
         self.use_complexity_bias = use_complexity_bias
+        self.tables = None
+
+    def route(self, x, freq_emb):
+        """-> (gates, top-k indices, top-k values, aux [1], gate of every dispatched row, index tables)."""
+        pooled = _GapFn.apply(x.contiguous())                                 # native GAP, fp32 [B, C]
+        noise = torch.randn_like(pooled[:, :1].expand(-1, self.num_experts))   # N(0,1) draw, train AND eval (:741)
+        cx = self.complexity.float() * self.tau if self.use_complexity_bias else None
+        out = _apply(_RouteFn, pooled, freq_emb.float().contiguous(), self.gate[2].weight, self.freq_gate.weight,
+                     noise.float().contiguous(), cx, self.k, self.training)
+        gates, idx, vals, aux, rowg = out[:5]
+        tb = ops.RouteTables()
+        tb.counts, tb.offsets, tb.perm, tb.perm_expert, tb.row_of = out[5:]
+        tb.perm_gate = rowg
+        self.tables = tb
+        return gates, idx, vals, aux, rowg, tb
 
     def forward(self, x, freq_emb):
-        pooled = _GapFn.apply(x.contiguous())                     # native GAP, fp32 [B, C]
-        logits = self.gate[2](pooled) + self.freq_gate(freq_emb.float())
-        if self.training:
-            loss_imp = self.importance_loss(logits.softmax(dim=-1))
-        noise = torch.randn_like(logits) * self.noise_std          # train AND eval, as the reference (moce_ir.py:741)
-        noisy_logits = logits + noise
-        gating_scores = noisy_logits.softmax(dim=-1)
-        top_k_values, top_k_indices = torch.topk(gating_scores, self.k, dim=-1)
-        if self.training:
-            loss_load = self.load_loss(logits, noisy_logits, self.noise_std)
-            aux_loss = 0.5 * loss_imp + 0.5 * loss_load
-        else:
-            aux_loss = 0
-        gates = torch.zeros_like(logits).scatter_(1, top_k_indices, top_k_values)
-        return gates, top_k_indices, top_k_values, aux_loss
+        gates, idx, vals, aux, _, _ = self.route(x, freq_emb)
+        return gates, idx, vals, (aux[0] if self.training else 0)
 
-    def importance_loss(self, gating_scores):
-        importance = gating_scores.sum(dim=0)
-        importance = importance * (self.complexity * self.tau) if self.use_complexity_bias else importance
-        return (importance.std() / (importance.mean() + 1e-8)) ** 2
 
-    def load_loss(self, logits, logits_noisy, noise_std):
-        thresholds = torch.topk(logits_noisy, self.k, dim=-1).indices[:, -1]
-        threshold_per_item = torch.sum(F.one_hot(thresholds, self.num_experts) * logits_noisy, dim=-1)
-        noise_required_to_win = (threshold_per_item.unsqueeze(-1) - logits) / noise_std
-        p = 1. - Normal(0, 1).cdf(noise_required_to_win)
-        p_mean = p.mean(dim=0)
-        return (p_mean.std() / (p_mean.mean() + 1e-8)) ** 2
+def _ladder(kind, base, n, dim=None):
+    """Per-expert depth / rank schedules (:616-644)."""
+    if isinstance(kind, int):
+        return [kind] * n
+    steps = {"lin": lambda i: base + i, "double": lambda i: base + 2 * i, "constant": lambda i: base}
+    if kind in steps:
+        return [steps[kind](i) for i in range(n)]
+    return None
 
 
 class AdapterLayer(nn.Module):
-    """E experts of growing rank/patch/kernel behind the noisy top-k router, then a 1x1 projection (moce_ir.py:584-681)."""
+    """E experts of growing rank / patch / kernel behind the noisy top-k router, then a 1x1 projection (:584-681)."""
 
     def __init__(self, dim: int, rank: int, num_experts: int = 4, top_k: int = 2, expert_layer: nn.Module = FFTAttention,
                  stage_depth: int = 1, depth_type: str = "lin", rank_type: str = "constant", freq_dim: int = 128,
@@ -286,67 +446,42 @@ class AdapterLayer(nn.Module):
         self.top_k = top_k
         self.noise_eps = 1e-2
         self.num_experts = num_experts
-        patch_sizes = [2 ** (i + 2) for i in range(num_experts)]
-        kernel_sizes = [3 + (2 * i) for i in range(num_experts)]
-        if depth_type == "lin":
-            depths = [stage_depth + i for i in range(num_experts)]
-        elif depth_type == "double":
-            depths = [stage_depth + (2 * i) for i in range(num_experts)]
-        elif depth_type == "exp":
-            depths = [2 ** (i) for i in range(num_experts)]
-        elif depth_type == "fact":
-            depths = [math.factorial(i + 1) for i in range(num_experts)]
-        elif isinstance(depth_type, int):
-            depths = [depth_type for _ in range(num_experts)]
-        elif depth_type == "constant":
-            depths = [stage_depth for i in range(num_experts)]
-        else:
-            raise NotImplementedError
-        if rank_type == "constant":
-            ranks = [rank for _ in range(num_experts)]
-        elif rank_type == "lin":
-            ranks = [rank + i for i in range(num_experts)]
-        elif rank_type == "double":
-            ranks = [rank + (2 * i) for i in range(num_experts)]
-        elif rank_type == "exp":
-            ranks = [rank ** (i + 1) for i in range(num_experts)]
-        elif rank_type == "fact":
-            ranks = [math.factorial(rank + i) for i in range(num_experts)]
-        elif rank_type == "spread":
-            ranks = [dim // (2 ** i) for i in range(num_experts)][::-1]
-        else:
+        E = num_experts
+        depths = _ladder(depth_type, stage_depth, E)
+        if depths is None:
+            depths = {"exp": [2 ** i for i in range(E)], "fact": [math.factorial(i + 1) for i in range(E)]}.get(depth_type)
+        ranks = _ladder(rank_type, rank, E)
+        if ranks is None:
+            ranks = {"exp": [rank ** (i + 1) for i in range(E)], "fact": [math.factorial(rank + i) for i in range(E)],
+                     "spread": [dim // (2 ** (E - 1 - i)) for i in range(E)]}.get(rank_type)
+        if depths is None or ranks is None or isinstance(rank_type, int):
             raise NotImplementedError
         self.experts = nn.ModuleList([
-            MySequential(*[ModExpert(dim, rank=rank, func=expert_layer, depth=depth, patch_size=patch, kernel_size=kernel)])
-            for idx, (depth, rank, patch, kernel) in enumerate(zip(depths, ranks, patch_sizes, kernel_sizes))
-        ])
+            MySequential(ModExpert(dim, rank=ranks[i], func=expert_layer, depth=depths[i], patch_size=2 ** (i + 2),
+                                   kernel_size=3 + 2 * i)) for i in range(E)])
         self.proj_out = nn.Conv2d(dim, dim, kernel_size=1, padding=0, bias=False)
         expert_complexity = torch.tensor([sum(p.numel() for p in expert.parameters()) for expert in self.experts])
-        self.routing = RoutingFunction(dim, freq_dim, num_experts=num_experts, k=top_k, complexity=expert_complexity,
+        self.routing = RoutingFunction(dim, freq_dim, num_experts=E, k=top_k, complexity=expert_complexity,
                                        use_complexity_bias=with_complexity, complexity_scale=complexity_scale)
 
     def forward(self, x, freq_emb, shared):
-        gates, top_k_indices, top_k_values, aux_loss = self.routing(x, freq_emb)
-        self.loss = aux_loss
-        if self.training:
-            dispatcher = SparseDispatcher(self.num_experts, gates)
-            expert_inputs = dispatcher.dispatch(x)
-            expert_shared_intputs = dispatcher.dispatch(shared)
-            expert_outputs = [self.experts[exp](expert_inputs[exp], expert_shared_intputs[exp])
-                              for exp in range(len(self.experts))]
-            out = dispatcher.combine(expert_outputs, multiply_by_gates=True)
-        else:                                   # B == 1 semantics of the reference's test path (moce_ir.py:674-678)
-            selected_experts = [self.experts[i] for i in top_k_indices.squeeze(0)]
-            expert_outputs = torch.stack([expert(x, shared) for expert in selected_experts], dim=1)
-            gates = gates.gather(1, top_k_indices)
-            weighted_outputs = gates.unsqueeze(2).unsqueeze(3).unsqueeze(4) * expert_outputs
-            out = weighted_outputs.sum(dim=1)
-        # combine accumulates in fp32 (moce_ir.py:123); hand the next 1x1 the activation dtype again
-        return _c1(out.to(x.dtype).contiguous(), self.proj_out)
+        gates, idx, vals, aux, row_gate, tb = self.routing.route(x, freq_emb)
+        self.loss = aux[0] if self.training else 0
+        counts = tuple(tb.counts.tolist())            # E segment sizes: the ragged expert launches are enqueued from the host
+        xrows = _RowsGatherFn.apply(x.contiguous(), tb.perm)
+        srows = _RowsGatherFn.apply(shared.contiguous(), tb.perm)
+        inner: List[Optional[Tensor]] = []
+        o = 0
+        for e, n in enumerate(counts):
+            inner.append(self.experts[e][0].inner(xrows[o:o + n], srows[o:o + n]) if n else None)
+            o += n
+        rows_out = _apply(_ExpertsOutFn, xrows, counts, *inner, *[ex[0].proj[2].weight for ex in self.experts])
+        out = _RowsCombineFn.apply(rows_out, row_gate, tb.perm, x.shape[0])     # gate multiply + fp32 scatter-add (:116-124)
+        return _c1(out.to(x.dtype), self.proj_out)
 
 
 class EncoderBlock(nn.Module):
-    """x + mixer(norms[0](x)); + ffn(norms[1](.))  (moce_ir.py:805-834): the Restormer block under MoCE's names."""
+    """x + mixer(norms[0](x)); + ffn(norms[1](.))  (:805-834): the Restormer block under MoCE's names."""
 
     def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
         super().__init__()
@@ -360,7 +495,7 @@ class EncoderBlock(nn.Module):
 
 
 class DecoderBlock(nn.Module):
-    """Shared MDTA + MoCE adapter + cross-MDTA mixer + GDFN (moce_ir.py:839-897).  Returns (x, adapter.loss)."""
+    """Shared MDTA + MoCE adapter + cross-MDTA mixer + GDFN (:839-897).  Returns (x, adapter.loss)."""
 
     def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type, expert_layer, complexity_scale=None,
                  rank=None, num_experts=None, top_k=None, depth_type=None, rank_type=None, stage_depth=None,
@@ -385,3 +520,140 @@ class DecoderBlock(nn.Module):
         x = self.mixer(x_a, x_s) + shortcut
         x = x + self.ffn(self.norms[1](x))
         return x, self.adapter.loss
+
+
+class HighPassConv2d(nn.Module):
+    """Depthwise 3x3 initialised to the 8-neighbour Laplacian (:224-249).  (The reference's ``freeze`` flag assigns an
+    attribute instead of calling ``requires_grad_``, so the kernel stays trainable there - and here.)"""
+
+    def __init__(self, c, freeze):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels=c, out_channels=c, kernel_size=3, padding=1, bias=False, groups=c)
+        lap = -torch.ones(3, 3)
+        lap[1, 1] = 8.0
+        with torch.no_grad():
+            self.conv.weight.copy_(lap.expand(c, 1, 3, 3))
+
+    def forward(self, x):
+        return _dw(x, self.conv)
+
+
+def _linear_rows(x: Tensor, lin: nn.Linear) -> Tensor:
+    """nn.Linear on [B, D] rows through the pointwise GEMM: the rows become the pixels of a one-image plane."""
+    xt = x.t().contiguous().view(1, x.shape[1], 1, x.shape[0])
+    y = _apply(_Conv1x1Fn, xt, None, lin.weight.view(lin.out_features, lin.in_features, 1, 1), lin.bias)
+    return y.view(lin.out_features, x.shape[0]).t()
+
+
+class FrequencyEmbedding(nn.Module):
+    """High-pass -> GELU -> global mean -> Linear / GELU / Linear on the latent features (:1048-1075)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.high_conv = nn.Sequential(HighPassConv2d(dim, freeze=True), nn.GELU())
+        self.mlp = nn.Sequential(nn.Linear(dim, 2 * dim), nn.GELU(), nn.Linear(2 * dim, dim))
+
+    def forward(self, x):
+        pooled = _GeluGapFn.apply(self.high_conv[0](x).contiguous())          # [B, dim] fp32 ; GELU + mean in one pass
+        h = _linear_rows(pooled, self.mlp[0])
+        return _linear_rows(F.gelu(h), self.mlp[2])
+
+
+class EncoderResidualGroup(nn.Module):
+    """``num_blocks`` EncoderBlocks in a row (:926-958)."""
+
+    def __init__(self, dim: int, num_heads: List[int], num_blocks: int, ffn_expansion: int, LayerNorm_type: str, bias: bool):
+        super().__init__()
+        self.loss = None
+        self.num_blocks = num_blocks
+        self.layers = nn.ModuleList([EncoderBlock(dim, num_heads, ffn_expansion, bias, LayerNorm_type)
+                                     for _ in range(num_blocks)])
+
+    def forward(self, x):
+        self.loss = 0
+        for blk in self.layers:
+            x = blk(x)
+        return x
+
+
+class DecoderResidualGroup(nn.Module):
+    """``num_blocks`` DecoderBlocks in a row; ``loss`` sums their routers' auxiliary losses (:962-1013)."""
+
+    def __init__(self, dim: int, num_heads: List[int], num_blocks: int, ffn_expansion: int, LayerNorm_type: str, bias: bool,
+                 complexity_scale=None, rank=None, num_experts=None, expert_layer=None, top_k=None, depth_type=None,
+                 stage_depth=None, rank_type=None, freq_dim: int = 128, with_complexity: bool = False):
+        super().__init__()
+        self.loss = None
+        self.num_blocks = num_blocks
+        self.layers = nn.ModuleList([
+            DecoderBlock(dim, num_heads, ffn_expansion, bias, LayerNorm_type, expert_layer=expert_layer, rank=rank,
+                         num_experts=num_experts, top_k=top_k, stage_depth=stage_depth, freq_dim=freq_dim,
+                         complexity_scale=complexity_scale, depth_type=depth_type, rank_type=rank_type,
+                         with_complexity=with_complexity) for _ in range(num_blocks)])
+
+    def forward(self, x, freq_emb=None):
+        total = 0
+        for blk in self.layers:
+            x, aux = blk(x, freq_emb)
+            total = total + aux
+        self.loss = total
+        return x
+
+
+class MoCEIR(nn.Module):
+    """The MoCE-IR U-Net (:1080-1231): encoder groups -> latent -> frequency embedding -> MoCE decoder groups -> refinement
+    -> 3x3 output + input.  ``total_loss`` holds the mean auxiliary (load-balance) loss of the decoder blocks after a forward."""
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=32, levels: int = 4, heads=[1, 1, 1, 1], num_blocks=[1, 1, 1, 3],
+                 num_dec_blocks=[1, 1, 1], ffn_expansion_factor=2, num_refinement_blocks=1, LayerNorm_type='WithBias',
+                 bias=False, rank=2, num_experts=4, depth_type="lin", stage_depth=[3, 2, 1], rank_type="constant", topk=1,
+                 expert_layer=FFTAttention, with_complexity=False, complexity_scale="max"):
+        super().__init__()
+        self.levels = levels
+        self.num_blocks = num_blocks
+        self.num_dec_blocks = num_dec_blocks
+        self.num_refinement_blocks = num_refinement_blocks
+        widths = [dim << i for i in range(levels)]
+        self.patch_embed = OverlapPatchEmbed(in_c=inp_channels, embed_dim=dim, bias=False)
+        self.freq_embed = FrequencyEmbedding(widths[-1])
+        self.enc = nn.ModuleList([
+            nn.ModuleList([EncoderResidualGroup(dim=widths[i], num_blocks=num_blocks[i], num_heads=heads[i],
+                                                ffn_expansion=ffn_expansion_factor, LayerNorm_type=LayerNorm_type, bias=True),
+                           Downsample(widths[i])]) for i in range(levels - 1)])
+        self.latent = EncoderResidualGroup(dim=widths[-1], num_blocks=num_blocks[-1], num_heads=heads[-1],
+                                           ffn_expansion=ffn_expansion_factor, LayerNorm_type=LayerNorm_type, bias=True)
+        self.dec = nn.ModuleList([])
+        for j in range(levels - 1):                   # decoder stage j works at level (levels - 2 - j)
+            lvl = levels - 2 - j
+            self.dec.append(nn.ModuleList([
+                Upsample(widths[lvl + 1]),
+                nn.Conv2d(widths[lvl + 1], widths[lvl], kernel_size=1, bias=bias),
+                DecoderResidualGroup(dim=widths[lvl], num_blocks=num_dec_blocks[levels - 2 - j], num_heads=heads[lvl],
+                                     ffn_expansion=ffn_expansion_factor, LayerNorm_type=LayerNorm_type, bias=bias,
+                                     expert_layer=expert_layer, freq_dim=widths[-1], with_complexity=with_complexity, rank=rank,
+                                     num_experts=num_experts, stage_depth=stage_depth[j], depth_type=depth_type,
+                                     rank_type=rank_type, top_k=topk, complexity_scale=complexity_scale)]))
+        self.refinement = EncoderResidualGroup(dim=dim, num_blocks=num_refinement_blocks, num_heads=heads[0],
+                                               ffn_expansion=ffn_expansion_factor, LayerNorm_type=LayerNorm_type, bias=True)
+        self.output = nn.Conv2d(dim, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.total_loss = None
+
+    def forward(self, x, labels=None):
+        feats = self.patch_embed(x)
+        skips = []
+        for group, down in self.enc:
+            feats = group(feats)
+            skips.append(feats)
+            feats = down(feats)
+        feats = self.latent(feats)
+        freq_emb = self.freq_embed(feats)
+        aux = 0
+        for up, fuse, group in self.dec:
+            # fusion(cat([up(feats), skip])) as ONE two-panel 1x1 GEMM: the concatenated tensor never exists (:1222)
+            feats = _apply(_Conv1x1Fn, up(feats), skips.pop(), fuse.weight, fuse.bias)
+            feats = group(feats, freq_emb)
+            aux = aux + group.loss
+        feats = self.refinement(feats)
+        out = _conv2d(feats, self.output, x)          # 3x3 output conv with the input residual in its epilogue (:1228)
+        self.total_loss = aux / sum(self.num_dec_blocks)
+        return out

@@ -146,7 +146,7 @@ def dwconv_gate_bwd_recompute(dg: Tensor, x: Tensor, w: Tensor, bias: Optional[T
 
 
 def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-            transposed: bool = False, x2: Optional[Tensor] = None) -> Tensor:
+            transposed: bool = False, x2: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """y = W x (+bias)(+residual).  x [B,K,H,W]; w [M,K(,1,1)] or, transposed, [K,M(,1,1)] used as W^T.
     x2: optional second K-panel (channel concat without the concat)."""
     _gpu(x, w, bias, residual, x2)
@@ -157,7 +157,8 @@ def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     w2 = w.reshape(w.shape[0], -1)
     M = w2.shape[1] if transposed else w2.shape[0]
     assert (w2.shape[0] if transposed else w2.shape[1]) == K1 + K2, "weight/input channel mismatch"
-    y = torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, M, H, W), dtype=x.dtype, device=x.device) if out is None else out
+    assert y.shape == (B, M, H, W) and y.is_contiguous() and y.dtype == x.dtype
     d = L.PwDesc()
     d.x1, d.x1_bs, d.x1_gs, d.k1 = _p(x), K1 * N, 0, K1
     d.x2, d.x2_bs, d.x2_gs, d.k2 = _p(x2), K2 * N, 0, K2
@@ -446,11 +447,122 @@ def gap_fwd(x: Tensor) -> Tensor:
 
 
 def gap_bwd(dout: Tensor, like: Tensor) -> Tensor:
+    dout = dout.contiguous()
     _gpu(dout, like)
     B, Cc, H, W = like.shape
     dx = torch.empty_like(like)
     L.check(L.lib().mi_gap_bwd(_p(dout.contiguous().float()), _p(dx), B, Cc, H * W, _dt(like), _stream()), "gap_bwd")
     return dx
+
+
+# ----------------------------------------------------------------------------- MoCE kernels (csrc/moce.hip)
+class RouteTables:
+    """Device-side SparseDispatcher bookkeeping produced by the router launch (no nonzero / sort / tolist)."""
+    __slots__ = ("counts", "offsets", "perm", "perm_gate", "perm_expert", "row_of", "logits")
+
+
+def moe_route_fwd(pooled: Tensor, freq: Tensor, wg: Tensor, wf: Tensor, noise: Tensor, complexity: Optional[Tensor], k: int,
+                  training: bool):
+    """-> gates [B,E], topk_idx [B,k] int64, topk_val [B,k], aux [1], RouteTables."""
+    _gpu(pooled, freq, wg, wf, noise, complexity)
+    for t in (pooled, freq, wg, wf, noise, complexity):
+        _f32(t, "router tensor")
+    B, Cc = pooled.shape
+    Fd, E = freq.shape[1], wg.shape[0]
+    dev = pooled.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    gates, aux = torch.empty((B, E), **f32), torch.empty(1, **f32)
+    idx = torch.empty((B, k), dtype=torch.int64, device=dev)
+    val = torch.empty((B, k), **f32)
+    tb = RouteTables()
+    tb.logits = torch.empty((B, E), **f32)
+    tb.counts = torch.empty(E, dtype=torch.int32, device=dev)
+    tb.offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    tb.perm = torch.empty(B * k, dtype=torch.int64, device=dev)
+    tb.perm_gate = torch.empty(B * k, **f32)
+    tb.perm_expert = torch.empty(B * k, dtype=torch.int32, device=dev)
+    tb.row_of = torch.empty((B, k), dtype=torch.int32, device=dev)
+    L.check(L.lib().mi_moe_route_fwd(_p(pooled), _p(freq), _p(wg), _p(wf), _p(noise), _p(complexity), _p(tb.logits), _p(gates),
+                                     _p(idx), _p(val), _p(aux), _p(tb.counts), _p(tb.offsets), _p(tb.perm), _p(tb.perm_gate),
+                                     _p(tb.perm_expert), _p(tb.row_of), B, Cc, Fd, E, k, int(training), _stream()),
+            "moe_route_fwd")
+    return gates, idx, val, aux, tb
+
+
+def moe_route_bwd(pooled: Tensor, freq: Tensor, wg: Tensor, wf: Tensor, noise: Tensor, complexity: Optional[Tensor],
+                  tb: RouteTables, idx: Tensor, dgates: Optional[Tensor], drow: Optional[Tensor], daux: Optional[Tensor],
+                  training: bool):
+    _gpu(pooled, freq, wg, wf, noise, complexity, dgates, drow, daux)
+    B, Cc = pooled.shape
+    Fd, E, k = freq.shape[1], wg.shape[0], idx.shape[1]
+    dpooled, dfreq, dwg, dwf = (torch.empty_like(t) for t in (pooled, freq, wg, wf))
+    L.check(L.lib().mi_moe_route_bwd(_p(pooled), _p(freq), _p(wg), _p(wf), _p(noise), _p(complexity), _p(tb.logits), _p(idx),
+                                     _p(_f32(dgates, "dgates")), _p(_f32(drow, "drow")), _p(tb.row_of), _p(_f32(daux, "daux")),
+                                     _p(dpooled), _p(dfreq), _p(dwg), _p(dwf), B, Cc, Fd, E, k, int(training), _stream()),
+            "moe_route_bwd")
+    return dpooled, dfreq, dwg, dwf
+
+
+def _bstride(t: Tensor) -> int:
+    """Batch stride (elements) of a [B,C,H,W] tensor whose [C,H,W] block is dense (a channel slice of a wider tensor)."""
+    B, Cc, H, W = t.shape
+    assert t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W, "need dense [C,H,W] blocks"
+    return t.stride(0) if B > 1 else Cc * H * W
+
+
+def patch_circconv(x: Tensor, y: Tensor, patch: int, flip: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Per patch x patch block: irfft2(rfft2(x) * rfft2(y)) = 2-D circular convolution (zero padded to the patch grid).
+    x, y: [B,C,H,W] (channel slices allowed); flip convolves with the index-reversed y (gradient form)."""
+    for t in (x, y):
+        if not t.is_cuda:
+            raise RuntimeError("image_restoration_amd ops run on the MI355X only (got a CPU tensor)")
+    B, Cc, H, W = x.shape
+    assert x.shape == y.shape and x.dtype == y.dtype
+    if out is None:
+        out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    L.check(L.lib().mi_patch_circconv(_p(x), _bstride(x), _p(y), _bstride(y), _p(out), _bstride(out), B, Cc, H, W, int(patch),
+                                      int(flip), _dt(x), _stream()), "patch_circconv")
+    return out
+
+
+def gelu_gap_fwd(x: Tensor) -> Tensor:
+    _gpu(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.lib().mi_gelu_gap_fwd(_p(x), _p(out), B, Cc, H * W, _dt(x), _stream()), "gelu_gap_fwd")
+    return out
+
+
+def gelu_gap_bwd(x: Tensor, dout: Tensor) -> Tensor:
+    dout = dout.contiguous()
+    _gpu(x, dout)
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().mi_gelu_gap_bwd(_p(x), _p(dout.contiguous().float()), _p(dx), B, Cc, H * W, _dt(x), _stream()), "gelu_gap_bwd")
+    return dx
+
+
+def ewise_fwd(a: Tensor, b: Tensor, op: int) -> Tensor:
+    """op 0: a * b ; op 1: a * silu(b).  a, b: [B,C,H,W], channel slices allowed."""
+    B = a.shape[0]
+    Ln = a[0].numel()
+    out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    L.check(L.lib().mi_ewise_fwd(_p(a), _bstride(a), _p(b), _bstride(b), _p(out), B, Ln, op, _dt(a), _stream()), "ewise_fwd")
+    return out
+
+
+def ewise_bwd(a: Tensor, b: Tensor, dout: Tensor, op: int, da: Optional[Tensor] = None, db: Optional[Tensor] = None):
+    """Gradients of ewise_fwd; da / db may be given as (channel-slice) views to be written in place."""
+    _gpu(dout)
+    B = a.shape[0]
+    Ln = a[0].numel()
+    if da is None:
+        da = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    if db is None:
+        db = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    L.check(L.lib().mi_ewise_bwd(_p(a), _bstride(a), _p(b), _bstride(b), _p(dout), _p(da), _bstride(da), _p(db), _bstride(db), B,
+                                 Ln, op, _dt(a), _stream()), "ewise_bwd")
+    return da, db
 
 
 # ----------------------------------------------------------------------------- training-step tail

@@ -272,6 +272,52 @@ int mi_rows_dot(const float* g, const void* src, const int64_t* idx, float* out,
                 void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * MoCE router in one launch each way (moce_ir.py:684-800 RoutingFunction; :82-91 SparseDispatcher index bookkeeping).
+ *   fwd: logits = pooled . Wg^T + freq . Wf^T  (pooled = GAP of the adapter input, [B,C]; freq = frequency embedding [B,F]);
+ *        noisy = logits + noise / E  (noise: the caller's N(0,1) draw, [B,E], applied in train AND eval as the reference does);
+ *        scores = softmax(noisy); top-k -> topk_idx [B,k] (int64), topk_val [B,k]; gates [B,E] = scores scattered at the top-k;
+ *        aux[0] = 0.5 CV^2(sum_b softmax(logits) * complexity) + 0.5 CV^2(mean_b (1 - Phi((thr_b - logits) * E)))  when
+ *        training != 0 (complexity may be NULL = no complexity bias), else 0;
+ *        dispatch tables: counts[E], offsets[E+1], and for the B*k dispatched rows grouped by expert (samples ascending within
+ *        an expert): perm (sample index, int64), perm_gate (its gate value), perm_expert; row_of [B,k] = the dispatched row
+ *        of sample b's j-th choice.
+ *   bwd: given dgates [B,E] (may be NULL), drow [B*k] (gradient of perm_gate, may be NULL) and daux (device scalar, may be
+ *        NULL): dpooled [B,C], dfreq [B,F], dwg [E,C], dwf [E,F] (overwritten).  E <= 8, B*E <= 8192.
+ * ------------------------------------------------------------------------ */
+int mi_moe_route_fwd(const float* pooled, const float* freq, const float* wg, const float* wf, const float* noise,
+                     const float* complexity, float* logits, float* gates, int64_t* topk_idx, float* topk_val, float* aux,
+                     int* counts, int* offsets, int64_t* perm, float* perm_gate, int* perm_expert, int* row_of, int B, int C, int F,
+                     int E, int k, int training, void* stream);
+int mi_moe_route_bwd(const float* pooled, const float* freq, const float* wg, const float* wf, const float* noise,
+                     const float* complexity, const float* logits, const int64_t* topk_idx, const float* dgates,
+                     const float* drow, const int* row_of, const float* daux, float* dpooled, float* dfreq, float* dwg, float* dwf,
+                     int B, int C, int F, int E, int k, int training, void* stream);
+
+/* ------------------------------------------------------------------------
+ * FFTAttention's patch spectrum product (moce_ir.py:408-414): irfft2(rfft2(x) * rfft2(y)) over every patch x patch block of
+ * each [H,W] plane = the 2-D circular convolution  out[u][v] = sum_{a,b} x[a][b] y[(u-a)%p][(v-b)%p], evaluated directly in
+ * fp32 from/to NCHW planes (zero padded to the patch grid at the bottom/right edge, cropped back; patch in {4,8,16,32}).
+ * flip != 0 uses y'[i][j] = y[-i][-j]: dx = circconv(dout, y, flip=1), dy = circconv(dout, x, flip=1).
+ * x_bs / y_bs / out_bs: batch strides in elements (0 = C*H*W), so that channel slices of a wider tensor (k of kv, the
+ * k half of d_kv) need no copy.
+ * ------------------------------------------------------------------------ */
+int mi_patch_circconv(const void* x, int64_t x_bs, const void* y, int64_t y_bs, void* out, int64_t out_bs, int B, int C, int H,
+                      int W, int patch, int flip, int dtype, void* stream);
+
+/* FrequencyEmbedding's GELU -> spatial mean (moce_ir.py:1062-1064,1071-1073): out[b,c] = mean_n gelu(x[b,c,n]) (fp32);
+ * bwd: dx = dout[b,c]/N * gelu'(x). */
+int mi_gelu_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtype, void* stream);
+int mi_gelu_gap_bwd(const void* x, const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream);
+
+/* Gating products of the expert path: op 0  out = a * b  (FFTAttention `out * v`, moce_ir.py:419);
+ * op 1  out = a * silu(b)  (ModExpert `body(x) * silu(proj[1](shared))`, :555).  bwd writes da and db. */
+/* a, b (and da, db) are [rows][L] with row strides in elements (0 = L); out and dout are contiguous [rows][L]. */
+int mi_ewise_fwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, void* out, int64_t rows, int64_t L, int op, int dtype,
+                 void* stream);
+int mi_ewise_bwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, const void* dout, void* da, int64_t da_rs, void* db,
+                 int64_t db_rs, int64_t rows, int64_t L, int op, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * U-Net glue, thin dense 3x3 convolutions (Restormer.py:156-165 OverlapPatchEmbed 3->48; :243,281 output conv 2*dim->3
  * + input residual).  Layout kernels that turn them into the 1x1 GEMM / Gram above:
  *   im2col3x3: x[B,C,H,W] -> col[B,9C,H,W], col[c*9+ky*3+kx][y][x] = x[c][y+ky-1][x+kx-1] (zero padded);

@@ -154,3 +154,11 @@ def decoder_block(x: Tensor, freq_emb: Tensor, sd: Dict[str, Tensor], heads: int
     x = x + gdfn(t, sd["ffn.project_in.weight"], sd["ffn.dwconv.weight"], sd["ffn.project_out.weight"],
                  g("ffn.project_in.bias"), g("ffn.dwconv.bias"), g("ffn.project_out.bias"))
     return x, aux
+
+
+def frequency_embedding(x: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """FrequencyEmbedding.forward (moce_ir.py:1070-1075): depthwise 3x3 high-pass -> GELU -> mean over the plane -> MLP."""
+    c = x.shape[1]
+    h = F.gelu(F.conv2d(x, sd["high_conv.0.conv.weight"], None, padding=1, groups=c)).mean(dim=(-2, -1))
+    h = F.gelu(F.linear(h, sd["mlp.0.weight"], sd["mlp.0.bias"]))
+    return F.linear(h, sd["mlp.2.weight"], sd["mlp.2.bias"])

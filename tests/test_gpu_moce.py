@@ -180,3 +180,170 @@ def test_dispatcher_native_rows_forward_and_backward(dtype):
     assert rel(out, ref) < tol
     assert rel(gx, xr.grad) < tol
     assert rel(gg, gr.grad) < tol
+
+
+# ------------------------------------------------------------------------------------------------ round 2: stand-alone pieces
+def _filled(mod, seed):
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if not k.endswith("complexity")}
+    mod.load_state_dict(R.make_state(shapes, seed), strict=False)
+    return mod
+
+
+@pytest.mark.parametrize("tag,r,p,shape", [("r12p8", 12, 8, (2, 12, 16, 16)), ("r24p16", 24, 16, (1, 24, 20, 12))])
+def test_fft_attention_standalone(tag, r, p, shape):
+    """FFTAttention alone (native patch circular convolution, ragged plane = the zero-padding path) vs the reference."""
+    import image_restoration_amd.moce_ir as mo
+    m = _filled(mo.FFTAttention(r, patch_size=p, kernel_size=3), 90 + r)
+    out, (dx,), g = run(m, [seeded_input(shape, 900 + r)], 910 + r)
+    gold = load(f"moce_fftattn_{tag}")
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3)
+    assert len(g) == len(list(m.parameters()))
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3, what="fftattn ")
+
+
+def test_mod_expert_standalone():
+    import image_restoration_amd.moce_ir as mo
+    m = _filled(mo.ModExpert(48, rank=12, func=mo.FFTAttention, depth=1, patch_size=8, kernel_size=5), 95)
+    out, (dx, dsh), g = run(m, [seeded_input((2, 48, 16, 16), 950), seeded_input((2, 48, 16, 16), 951)], 960)
+    gold = load("moce_modexpert_c48r12")
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3); check("dshared", dsh, gold, 1e-3)
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3, what="modexpert ")
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_adapter_layer_all_experts(k):
+    """AdapterLayer alone with a routing that uses all four experts (top-1) / hits every sample twice (top-2): every
+    expert's parameters receive the reference's gradient."""
+    import image_restoration_amd.moce_ir as mo
+    gold = load(f"moce_adapter_k{k}")
+    m = _filled(mo.AdapterLayer(48, rank=2, num_experts=4, top_k=k, expert_layer=mo.FFTAttention, stage_depth=1,
+                                depth_type="constant", rank_type="spread", freq_dim=64, with_complexity=True,
+                                complexity_scale="max"), 100 + k).train()
+    ins = [seeded_input((8, 48, 16, 16), 1000), seeded_input((8, 64), 1001), seeded_input((8, 48, 16, 16), 1002)]
+    with injected_noise(int(gold["noise_seed"])):
+        out, (dx, dfe, dsh), g = run(m, ins, 1010 + k)
+    assert np.array_equal(m.routing.tables.perm_expert.cpu().numpy().astype(np.int64).tolist(),
+                          sorted(int(e) for e in gold["idx"].reshape(-1)))
+    if k == 1:
+        assert sorted(set(int(e) for e in gold["idx"].reshape(-1))) == [0, 1, 2, 3]
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3); check("dshared", dsh, gold, 1e-3)
+    check("dfe", dfe, gold, 2e-3)
+    assert abs(float(m.loss) - float(gold["aux"])) < 1e-4
+    names = [n for n, _ in m.named_parameters()]
+    for name in names:
+        key = "g_" + name + ".l2"
+        if key not in gold.files:
+            continue
+        if float(gold[key]) < 1e-7:
+            assert name not in g or float(g[name].norm()) < 1e-5, name
+        else:
+            check("g_" + name, g[name], gold, 2e-3, what="adapter ")
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_router_kernel_gradients(k):
+    """mi_moe_route_bwd: gradients of sum(gates * cot) + aux w.r.t. the feature map, the frequency embedding and both gate
+    matrices against the reference's autograd (fp64)."""
+    import image_restoration_amd.moce_ir as mo
+    gold = load(f"moce_router_grads_k{k}")
+    comp = torch.tensor([18840., 42288., 103008., 279744.])
+    rf = mo.RoutingFunction(48, 64, num_experts=4, k=k, complexity=comp, use_complexity_bias=True, complexity_scale="max")
+    rf.load_state_dict(R.make_state({"gate.2.weight": (4, 48), "freq_gate.weight": (4, 64)}, 70 + k), strict=False)
+    rf = rf.to(DEV).train()
+    x = seeded_input((8, 48, 8, 8), 700).to(DEV).requires_grad_(True)
+    fe = seeded_input((8, 64), 701).to(DEV).requires_grad_(True)
+    with injected_noise(702):
+        gates, idx, vals, aux = rf(x, fe)
+    ((gates * seeded_input((8, 4), 703).to(DEV)).sum() + aux).backward()
+    check("gates", gates, gold, 1e-4)
+    assert abs(float(aux) - float(gold["aux"])) < 1e-4
+    check("dx", x.grad, gold, 1e-3); check("dfe", fe.grad, gold, 1e-3)
+    check("g_gate", rf.gate[2].weight.grad, gold, 1e-3); check("g_freq", rf.freq_gate.weight.grad, gold, 1e-3)
+
+
+def test_frequency_embedding():
+    import image_restoration_amd.moce_ir as mo
+    gold = load("moce_freqemb_d64")
+    m = mo.FrequencyEmbedding(64)
+    # the fixed Laplacian initialisation before any weights are loaded (moce_ir.py:241-243)
+    assert np.allclose(m.high_conv[0].conv.weight[5, 0].detach().numpy(), [[-1, -1, -1], [-1, 8, -1], [-1, -1, -1]])
+    m = _filled(m, 110)
+    out, (dx,), g = run(m, [seeded_input((2, 64, 8, 8), 1100)], 1110)
+    check("y", out, gold, 1e-3); check("dx", dx, gold, 1e-3)
+    for k, v in g.items():
+        check("g_" + k, v, gold, 1e-3, what="freqemb ")
+
+
+MOCEIR_TINY = dict(dim=16, levels=4, heads=[1, 2, 4, 8], num_blocks=[1, 1, 1, 2], num_dec_blocks=[1, 1, 1],
+                   num_refinement_blocks=1, rank=2, num_experts=4, depth_type="constant", stage_depth=[1, 1, 1],
+                   rank_type="spread", topk=1, with_complexity=True, complexity_scale="max")
+
+
+def test_moceir_whole_network_train_and_eval():
+    """BASELINE configs[3] (MoCE-IR) as a whole network at a reduced width: output, auxiliary loss, input gradient and the
+    gradient norm of EVERY parameter against the reference (train); batch-1 eval output."""
+    import image_restoration_amd.moce_ir as mo
+    gold = load("moceir_tiny_train")
+    keys = load("moceir_keys")
+    net = mo.MoCEIR(**MOCEIR_TINY)
+    assert list(net.state_dict()) == [str(k) for k in keys["tiny"]]
+    net = _filled(net, 120).to(DEV).train()
+    x = seeded_input((2, 3, 64, 64), 1200).to(DEV).requires_grad_(True)
+    with injected_noise(1201):
+        y = net(x)
+        loss = (y - seeded_input((2, 3, 64, 64), 1202).to(DEV)).abs().mean() + 0.01 * net.total_loss
+        loss.backward()
+    check("y", y, gold, 1e-3); check("dx", x.grad, gold, 2e-3)
+    assert abs(float(net.total_loss) - float(gold["total_loss"])) < 1e-4
+    assert abs(float(loss) - float(gold["loss"])) < 1e-4
+    ref_norms = dict(zip([str(n) for n in gold["grad_names"]], gold["grad_norms"]))
+    got = {n: p.grad for n, p in net.named_parameters()}
+    worst = 0.0
+    for n, rn in ref_norms.items():
+        if rn < 0:                       # the reference left this parameter without a gradient (expert nobody routed to)
+            assert got[n] is None or float(got[n].norm()) == 0.0, n
+            continue
+        gn = float(got[n].norm()) if got[n] is not None else 0.0
+        worst = max(worst, abs(gn - rn) / max(rn, 1e-6))
+        assert abs(gn - rn) <= 2e-3 * max(rn, 1e-6) + 1e-7, (n, gn, rn)
+    net.eval()
+    with torch.no_grad(), injected_noise(1203):
+        ye = net(x.detach()[:1])
+    check("y", ye, load("moceir_tiny_eval"), 1e-3)
+
+
+def test_moceir_base_state_dict_keys_and_size():
+    import image_restoration_amd.moce_ir as mo
+    keys = load("moceir_keys")
+    base = mo.MoCEIR(dim=48, num_blocks=[4, 6, 6, 8], num_dec_blocks=[2, 4, 4], levels=4, heads=[1, 2, 4, 8],
+                     num_refinement_blocks=4, topk=1, num_experts=4, rank=2, with_complexity=True, depth_type="constant",
+                     stage_depth=[1, 1, 1], rank_type="spread", complexity_scale="max")
+    assert list(base.state_dict()) == [str(k) for k in keys["base"]]
+    assert sum(p.numel() for p in base.parameters()) == int(keys["base_params"][0])
+
+
+@pytest.mark.parametrize("p,shape", [(4, (2, 5, 12, 20)), (8, (1, 7, 16, 24)), (16, (2, 3, 40, 33)), (32, (1, 2, 64, 300))])
+def test_patch_circconv_vs_fft(p, shape):
+    """mi_patch_circconv against irfft2(rfft2 * rfft2) in fp64 (ragged planes, >256-pixel rows), forward and the flipped
+    form the gradients use; also with the second operand a channel slice (no copy)."""
+    from image_restoration_amd import ops
+    import torch.nn.functional as Fn
+    b, c, h, w = shape
+    x = seeded_input(shape, 5000 + p).to(DEV)
+    wide = seeded_input((b, 2 * c, h, w), 5001 + p).to(DEV)
+    y = wide[:, c:]
+
+    def ref(a, bb):
+        def pat(t):
+            t = Fn.pad(t.double().cpu(), (0, (p - w % p) % p, 0, (p - h % p) % p))
+            return t.reshape(b, c, t.shape[-2] // p, p, t.shape[-1] // p, p).permute(0, 1, 2, 4, 3, 5)
+        o = torch.fft.irfft2(torch.fft.rfft2(pat(a)) * torch.fft.rfft2(pat(bb)), s=(p, p))
+        return o.permute(0, 1, 2, 4, 3, 5).reshape(b, c, o.shape[2] * p, o.shape[3] * p)[:, :, :h, :w]
+    assert rel(ops.patch_circconv(x, y, p), ref(x, y)) < 2e-5
+    # gradient form: d/dx sum(cot * circconv(x, y)) = circconv(cot, y, flip)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    cot = seeded_input(shape, 5002 + p)
+    (ref(xr, y) * cot.double()).sum().backward()
+    assert rel(ops.patch_circconv(cot.to(DEV), y, p, flip=True), xr.grad) < 2e-5
