@@ -484,7 +484,7 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   MI_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gram: grid too large");
   const bool ss = d->sumsq != nullptr;
   {
-    ProfScope ps(st, K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * 2.0 + 4.0 * g.splits * g.Z * d->ma * d->mb,
+    ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * 2.0 + 4.0 * g.splits * g.Z * d->ma * d->mb,
                  2.0 * d->ma * d->mb * (double)d->n * g.Z);
 #define GS_CASE(FA_, FB_)                                                                                           \
   if (g.fa == FA_ && g.fb == FB_) {                                                                                 \
@@ -543,7 +543,7 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   const bool ss = d->sumsq != nullptr;
   const double es = d->dtype == MI_BF16 ? 2.0 : 4.0;
   {
-  ProfScope ps(st, K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
+  ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
                2.0 * d->ma * d->mb * (double)d->n * g.Z);
 #define GRAM_CASE(T, F)                                                                     \
   do {                                                                                      \

@@ -982,7 +982,9 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
   const double Z = (double)d->batch * k.groups, kt = k.k1 + k.k2;
-  ProfScope ps(st, K_PW_GEMM, (kt + k.m + (k.r ? k.m : 0)) * (double)k.n * Z * sizeof(T) + 4.0 * k.m * kt,
+  // the forward attention product  out = M_b . v (+ x): per-image weights, one group, not transposed (modules.hip attn_core_fwd)
+  const bool is_av = d->w_bs != 0 && k.groups == 1 && d->w_sk == 1 && k.r != nullptr;
+  ProfScope ps(st, is_av ? K_PW_AV : K_PW_GEMM, (kt + k.m + (k.r ? k.m : 0)) * (double)k.n * Z * sizeof(T) + 4.0 * k.m * kt,
                2.0 * k.m * kt * (double)k.n * Z);
   // The LDS-DMA ring measured 5-12% SLOWER than register staging on every Restormer shape (K is 2-16 chunks, so the
   // per-tile prologue and epilogue dominate and its 3 x chunk LDS footprint halves the resident workgroups).  It stays

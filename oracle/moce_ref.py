@@ -14,7 +14,7 @@ from .restormer_ref import gdfn, layernorm_nchw, mdta, mdta_cross, sub_state
 
 Tensor = torch.Tensor
 
-__all__ = ["cross_attention", "fft_attention", "mod_expert", "routing", "dispatch_indices", "adapter_layer",
+__all__ = ["cross_attention", "fft_attention", "mod_expert", "routing", "dispatch_indices", "adapter_layer", "frequency_embedding",
            "encoder_block", "decoder_block", "expert_ranks"]
 
 
