@@ -141,6 +141,57 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ z,
   }
 }
 
+// PixelShuffle(2) / PixelUnshuffle(2) (Restormer.py:175-176,186-187) as one streaming pass with batch strides on both sides,
+// so that the shuffled map can land directly in (or be read back from) one half of the decoder's concatenation buffer.
+//   shuffle  : out[b][c][2y+i][2x+j] = in[b][4c+2i+j][y][x]      (in: [B,4c,H,W], out: [B,c,2H,2W])
+//   unshuffle: out[b][4c+2i+j][y][x] = in[b][c][2y+i][2x+j]      (in: [B,c,2H,2W], out: [B,4c,H,W])
+// A thread moves V pixels of one low-resolution row for both column phases j: two V-wide accesses on the planar side,
+// one 2V-wide interleaved access on the high-resolution side.
+template <typename T, int V, bool UNSHUFFLE>
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const T* __restrict__ in, T* __restrict__ out, int c, int H, int W,
+                                                            int64_t in_bs, int64_t out_bs, int64_t total) {
+  const int wv = W / V;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int64_t r = t;
+    const int xv = (int)(r % wv); r /= wv;
+    const int y = (int)(r % H); r /= H;
+    const int i = (int)(r % 2); r /= 2;
+    const int ch = (int)(r % c);
+    const int64_t b = r / c;
+    const int64_t lo0 = ((int64_t)(4 * ch + 2 * i) * H + y) * W + xv * V;        // planar side, phase j = 0 (j = 1: + H*W)
+    const int64_t hi = ((int64_t)ch * 2 * H + 2 * y + i) * 2 * W + 2 * xv * V;    // high-resolution side
+    float a0[V], a1[V], z[2 * V];
+    if (UNSHUFFLE) {
+      Vec<T, V>::ld(in + b * in_bs + hi, z);
+      Vec<T, V>::ld(in + b * in_bs + hi + V, z + V);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { a0[k] = z[2 * k]; a1[k] = z[2 * k + 1]; }
+      Vec<T, V>::st(out + b * out_bs + lo0, a0);
+      Vec<T, V>::st(out + b * out_bs + lo0 + (int64_t)H * W, a1);
+    } else {
+      Vec<T, V>::ld(in + b * in_bs + lo0, a0);
+      Vec<T, V>::ld(in + b * in_bs + lo0 + (int64_t)H * W, a1);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { z[2 * k] = a0[k]; z[2 * k + 1] = a1[k]; }
+      Vec<T, V>::st(out + b * out_bs + hi, z);
+      Vec<T, V>::st(out + b * out_bs + hi + V, z + V);
+    }
+  }
+}
+
+// dst[r][0..L) = src[r][0..L) with row strides (a channel slice of a wider NCHW tensor <-> a dense tensor)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, int64_t src_rs, T* __restrict__ dst,
+                                                        int64_t dst_rs, int64_t L, int64_t total) {
+  const int64_t lv = L / V;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / lv, c = (t - r * lv) * V;
+    float v[V];
+    Vec<T, V>::ld(src + r * src_rs + c, v);
+    Vec<T, V>::st(dst + r * dst_rs + c, v);
+  }
+}
+
 struct GPlan { int band, nb; unsigned blocks; };
 static GPlan g_plan(int H, int W, int64_t planes) {
   const int lpr = W / 4, G = 64 / lpr;
@@ -206,6 +257,51 @@ extern "C" int mi_col2im3x3(const void* z, const float* bias, const void* residu
     G_LPR_SWITCH(W, hipLaunchKernelGGL((col2im3x3_kernel<bf16, LPR>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)z, bias,
                                        (const bf16*)residual, (bf16*)y, (int)planes, M, H, W, p.nb, p.band, flip));
   }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_pixel_shuffle2(const void* in, int64_t in_bs, void* out, int64_t out_bs, int B, int c, int H, int W,
+                                 int unshuffle, int dtype, void* stream) {
+  MI_CHECK_ARG(in && out && B > 0 && c > 0 && H > 0 && W > 0, "pixel_shuffle2: bad arguments");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "pixel_shuffle2: bad dtype %d", dtype);
+  const int V = dtype == MI_BF16 ? 8 : 4;           // 16-byte accesses on the planar side
+  MI_CHECK_ARG(W % V == 0 && aligned16(in) && aligned16(out), "pixel_shuffle2: W must be a multiple of %d, pointers 16-byte aligned", V);
+  const int64_t dense_lo = (int64_t)4 * c * H * W;  // both sides hold 4*c*H*W elements per image
+  const int64_t ibs = in_bs ? in_bs : dense_lo, obs = out_bs ? out_bs : dense_lo;
+  MI_CHECK_ARG(ibs % V == 0 && obs % V == 0, "pixel_shuffle2: batch strides must keep 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)B * c * 2 * H * (W / V);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  ProfScope ps(st, K_COL2IM, 2.0 * B * dense_lo * dtype_size(dtype), 0.0);
+  if (dtype == MI_BF16) {
+    if (unshuffle) hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, 8, true>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, c, H, W, ibs, obs, total);
+    else hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, 8, false>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, c, H, W, ibs, obs, total);
+  } else {
+    if (unshuffle) hipLaunchKernelGGL((pixel_shuffle_kernel<float, 4, true>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, c, H, W, ibs, obs, total);
+    else hipLaunchKernelGGL((pixel_shuffle_kernel<float, 4, false>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, c, H, W, ibs, obs, total);
+  }
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_copy_rows(const void* src, int64_t src_rs, void* dst, int64_t dst_rs, int64_t rows, int64_t L, int dtype,
+                            void* stream) {
+  MI_CHECK_ARG(src && dst && rows > 0 && L > 0, "copy_rows: bad arguments");
+  MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "copy_rows: bad dtype %d", dtype);
+  const int V = dtype == MI_BF16 ? 8 : 4;
+  if (!src_rs) src_rs = L;
+  if (!dst_rs) dst_rs = L;
+  MI_CHECK_ARG(L % V == 0 && src_rs % V == 0 && dst_rs % V == 0 && aligned16(src) && aligned16(dst),
+               "copy_rows: rows must be 16-byte aligned and a multiple of 16 bytes long");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = rows * (L / V);
+  int blocks = cdiv(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  ProfScope ps(st, K_CAST, 2.0 * rows * L * dtype_size(dtype), 0.0);
+  if (dtype == MI_BF16) hipLaunchKernelGGL((copy_rows_kernel<bf16, 8>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, src_rs, (bf16*)dst, dst_rs, L, total);
+  else hipLaunchKernelGGL((copy_rows_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)src, src_rs, (float*)dst, dst_rs, L, total);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -438,6 +438,33 @@ def col2im3x3(z: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tenso
     return y
 
 
+def pixel_shuffle2(x: Tensor, unshuffle: bool, out: Optional[Tensor] = None) -> Tensor:
+    """PixelShuffle(2) (unshuffle False: [B,4c,H,W] -> [B,c,2H,2W]) or its inverse.  x / out may be channel slices of wider
+    tensors (dense [C,H,W] blocks, any batch stride)."""
+    if not x.is_cuda:
+        raise RuntimeError("image_restoration_amd ops run on the MI355X only (got a CPU tensor)")
+    B, Cx, Hx, Wx = x.shape
+    if unshuffle:
+        c, H, W = Cx, Hx // 2, Wx // 2
+        shape = (B, 4 * c, H, W)
+    else:
+        c, H, W = Cx // 4, Hx, Wx
+        shape = (B, c, 2 * H, 2 * W)
+    if out is None:
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    assert tuple(out.shape) == shape and out.dtype == x.dtype
+    L.check(L.lib().mi_pixel_shuffle2(_p(x), _bstride(x), _p(out), _bstride(out), B, c, H, W, int(unshuffle), _dt(x), _stream()),
+            "pixel_shuffle2")
+    return out
+
+
+def copy_rows(src: Tensor, dst: Tensor) -> Tensor:
+    """dst <- src for [B,C,H,W] tensors whose [C,H,W] blocks are dense (either may be a channel slice)."""
+    B = src.shape[0]
+    L.check(L.lib().mi_copy_rows(_p(src), _bstride(src), _p(dst), _bstride(dst), B, src[0].numel(), _dt(src), _stream()), "copy_rows")
+    return dst
+
+
 def gap_fwd(x: Tensor) -> Tensor:
     _gpu(x)
     B, Cc, H, W = x.shape

@@ -427,11 +427,11 @@ class TransformerBlock(nn.Module):
         return _apply(_BlockFn, x, self.attn.num_heads, *params)
 
 
-class _ThinConv3x3Fn(torch.autograd.Function):
-    """Dense 3x3 convolution (stride 1, pad 1) where one side has <= 4 channels, built from the native 1x1 GEMM / Gram plus
-    the im2col3x3 / col2im3x3 layout kernels (csrc/glue.hip).  These are Restormer's OverlapPatchEmbed (3 -> dim,
-    Restormer.py:156-165) and output conv (2*dim -> 3 plus the input residual, Restormer.py:243,281): pure HBM streams
-    that MIOpen's implicit-GEMM kernels run 10-20x off their roofline.
+class _Conv3x3Fn(torch.autograd.Function):
+    """Dense 3x3 convolution (stride 1, pad 1) built from the native 1x1 GEMM / Gram plus the im2col3x3 / col2im3x3 layout
+    kernels (csrc/glue.hip): Restormer's OverlapPatchEmbed (3 -> dim, Restormer.py:156-165), output conv (2*dim -> 3 plus the
+    input residual, :243,281) and the C -> C/2 / C -> 2C convs of Downsample / Upsample (:171-189).  The form with the
+    fewer expanded planes is taken (im2col when Cin <= Cout, col2im otherwise), so no vendor convolution runs in the step.
       Cin tiny : y = W[Cout,9Cin] . im2col(x);            dW = Gram(dy, im2col(x));  dx = col2im(W^T . dy)
       Cout tiny: y = col2im(Wz[9Cout,Cin] . x) (+b)(+res); dz = im2col_flipped(dy);   dx = Wz^T . dz;  dWz = Gram(dz, x)"""
 
@@ -447,8 +447,10 @@ class _ThinConv3x3Fn(torch.autograd.Function):
             wz = weight.permute(0, 2, 3, 1).reshape(cout * 9, cin).contiguous()      # [(co,ky,kx), ci]; a few KB
             y = ops.col2im3x3(ops.conv1x1(x, wz), bias, residual)
             saved = x
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(saved, weight)
+        if _grad_mode() and any(ctx.needs_input_grad):
+            # wide inputs: keep x and rebuild its 9-plane expansion in backward instead of holding 9 Cin planes per conv
+            ctx.recol = ctx.small_in and cin > 4
+            ctx.save_for_backward(x if ctx.recol else saved, weight)
             ctx.has_bias = bias is not None
             ctx.mg = _main_grads((weight, bias))
         return y
@@ -460,6 +462,8 @@ class _ThinConv3x3Fn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         dx = None
         if ctx.small_in:
+            if ctx.recol:
+                saved = ops.im2col3x3(saved)
             dw = ops.gram(dy, saved, 1, True)[0].reshape(weight.shape)                # [Cout, 9Cin]
             if ctx.needs_input_grad[0]:
                 dx = ops.col2im3x3(ops.conv1x1(dy, weight.reshape(cout, cin * 9), None, None, True), flip=True)
@@ -481,11 +485,11 @@ class _ThinConv3x3Fn(torch.autograd.Function):
 
 
 def _conv2d(x: Tensor, conv: nn.Conv2d, residual: Optional[Tensor] = None) -> Tensor:
-    """U-Net glue convolution (dense 3x3).  Thin ones (<= 4 channels on one side) are native
-    (_ThinConv3x3Fn); the C -> C/2 and C -> 2C convs of Down/Upsample are still a PyTorch-ROCm (MIOpen) op."""
-    if (min(conv.weight.shape[0], conv.weight.shape[1]) <= 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and x.is_cuda and ops.glue3x3_ok(x.shape[2], x.shape[3]) and x.is_contiguous()):
-        return _apply(_ThinConv3x3Fn, x, conv.weight, conv.bias, residual)
+    """U-Net glue convolution (dense 3x3): native (_Conv3x3Fn) on rows of 16..256 pixels (power of
+    two); other plane shapes fall back to the PyTorch-ROCm op."""
+    if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 and x.is_cuda
+            and ops.glue3x3_ok(x.shape[2], x.shape[3]) and x.is_contiguous()):
+        return _apply(_Conv3x3Fn, x, conv.weight, conv.bias, residual)
     y = _conv2d_torch(x, conv)
     return y if residual is None else y + residual
 
@@ -498,6 +502,57 @@ def _conv2d_torch(x: Tensor, conv: nn.Conv2d) -> Tensor:
     if b is not None and b.dtype != x.dtype:
         b = b.to(x.dtype)
     return F.conv2d(x, w, b, conv.stride, conv.padding)
+
+
+class _PixelShuffleFn(torch.autograd.Function):
+    """PixelShuffle(2) / PixelUnshuffle(2) as one native streaming pass; each is the other's backward."""
+
+    @staticmethod
+    def forward(ctx, x, unshuffle):
+        ctx.unshuffle = unshuffle
+        return ops.pixel_shuffle2(x, unshuffle)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.pixel_shuffle2(dy if ops_dense(dy) else dy.contiguous(), not ctx.unshuffle), None
+
+
+def ops_dense(t: Tensor) -> bool:
+    """[C,H,W] blocks dense (a channel slice of a contiguous NCHW tensor qualifies)."""
+    return t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
+
+
+class _UpCatFn(torch.autograd.Function):
+    """cat([PixelShuffle(2)(z), skip], 1)  (Restormer.py:185-189 Upsample body + :266 torch.cat) without an intermediate:
+    the shuffle writes straight into the first half of the concatenation buffer, the skip is copied into the second; the
+    backward un-shuffles the first half in place of a slice copy."""
+
+    @staticmethod
+    def forward(ctx, z, skip):
+        B, c4, H, W = z.shape
+        c = c4 // 4
+        out = torch.empty((B, c + skip.shape[1], 2 * H, 2 * W), dtype=z.dtype, device=z.device)
+        ops.pixel_shuffle2(z, False, out=out[:, :c])
+        ops.copy_rows(skip, out[:, c:])
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        c = ctx.c
+        dz = ops.pixel_shuffle2(dout[:, :c], True)
+        dskip = torch.empty((dout.shape[0], dout.shape[1] - c) + tuple(dout.shape[2:]), dtype=dout.dtype, device=dout.device)
+        ops.copy_rows(dout[:, c:], dskip)
+        return dz, dskip
+
+
+def _shuffle(x: Tensor, unshuffle: bool) -> Tensor:
+    V = 8 if x.dtype == torch.bfloat16 else 4
+    w_lo = x.shape[3] // 2 if unshuffle else x.shape[3]
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and w_lo % V == 0 and x.is_contiguous():
+        return _apply(_PixelShuffleFn, x, unshuffle)
+    return (F.pixel_unshuffle(x, 2) if unshuffle else F.pixel_shuffle(x, 2)).contiguous()
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -520,7 +575,7 @@ class Downsample(nn.Module):
                                   nn.PixelUnshuffle(2))
 
     def forward(self, x):
-        return F.pixel_unshuffle(_conv2d(x, self.body[0]), 2).contiguous()
+        return _shuffle(_conv2d(x, self.body[0]), True)
 
 
 class Upsample(nn.Module):
@@ -532,7 +587,16 @@ class Upsample(nn.Module):
                                   nn.PixelShuffle(2))
 
     def forward(self, x):
-        return F.pixel_shuffle(_conv2d(x, self.body[0]), 2).contiguous()
+        return _shuffle(_conv2d(x, self.body[0]), False)
+
+
+def _up_cat(up: "Upsample", x: Tensor, skip: Tensor) -> Tensor:
+    """torch.cat([up(x), skip], 1) (Restormer.py:265-266) with the shuffle writing into the concatenation buffer."""
+    z = _conv2d(x, up.body[0])
+    V = 8 if z.dtype == torch.bfloat16 else 4
+    if z.is_cuda and z.dtype in (torch.bfloat16, torch.float32) and z.shape[3] % V == 0 and skip.is_contiguous():
+        return _apply(_UpCatFn, z, skip)
+    return torch.cat([F.pixel_shuffle(z, 2), skip], 1)
 
 
 def _stage(dim, heads, n, ffn, bias, ln):
@@ -584,7 +648,7 @@ class Restormer(nn.Module):
         inp_dec_level2 = _apply(_Conv1x1Fn, self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
                                           self.reduce_chan_level2.bias)
         out_dec_level2 = self.decoder_level2(inp_dec_level2)
-        inp_dec_level1 = torch.cat([self.up2_1(out_dec_level2), out_enc_level1], 1)
+        inp_dec_level1 = _up_cat(self.up2_1, out_dec_level2, out_enc_level1)
         out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
 
         if self.dual_pixel_task:

@@ -332,6 +332,15 @@ int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip,
 int mi_col2im3x3(const void* z, const float* bias, const void* residual, void* y, int B, int M, int H, int W, int flip,
                  int dtype, void* stream);
 
+/* PixelShuffle(2) / PixelUnshuffle(2) of Upsample / Downsample (Restormer.py:171-189; moce_ir.py Downsample/Upsample):
+ *   unshuffle == 0: in [B,4c,H,W] -> out [B,c,2H,2W], out[b][c][2y+i][2x+j] = in[b][4c+2i+j][y][x]
+ *   unshuffle != 0: in [B,c,2H,2W] -> out [B,4c,H,W] (the inverse; also each other's backward).
+ * in_bs / out_bs: batch strides in elements (0 = dense), so the high-resolution side may be a channel slice of the decoder's
+ * concatenation buffer (Restormer.py:266 torch.cat).  mi_copy_rows moves [rows][L] with row strides (the skip half of it). */
+int mi_pixel_shuffle2(const void* in, int64_t in_bs, void* out, int64_t out_bs, int B, int c, int H, int W, int unshuffle,
+                      int dtype, void* stream);
+int mi_copy_rows(const void* src, int64_t src_rs, void* dst, int64_t dst_rs, int64_t rows, int64_t L, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * Router global average pool (moce_ir.py:703-707, RoutingFunction.gate[0]): out[b,c] = mean_n x[b,c,n] (fp32);
  * bwd: dx[b,c,:] = dout[b,c]/N.

@@ -235,7 +235,7 @@ def test_thin_glue_conv3x3_native(dtype, tol, cin, cout, hw, bias):
     yr.backward(cot.double())
     conv = conv.to(DEV)
     xg = x.to(DEV).to(dtype).requires_grad_(True)
-    assert isinstance(RM._conv2d(xg, conv, res.to(DEV).to(dtype)).grad_fn, RM._ThinConv3x3Fn._backward_cls)
+    assert isinstance(RM._conv2d(xg, conv, res.to(DEV).to(dtype)).grad_fn, RM._Conv3x3Fn._backward_cls)
     y = RM._conv2d(xg, conv, res.to(DEV).to(dtype))
     y.backward(cot.to(DEV).to(dtype))
     assert rel(y, yr) < tol
@@ -301,3 +301,43 @@ def test_alternate_kernel_paths_stay_correct(monkeypatch, env):
     assert rel(dx, xr.grad) < 2e-4
     for k, v in g.items():
         assert rel(v, sdr[k].grad) < (2e-3 if k.endswith("temperature") else 2e-4), k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("kind,c,hw", [("down", 48, (32, 64)), ("down", 96, (16, 32)), ("up", 96, (16, 32)), ("up", 64, (24, 16))])
+def test_down_up_sample_native(dtype, tol, kind, c, hw):
+    """Downsample (3x3 C -> C/2 + PixelUnshuffle) and Upsample (3x3 C -> 2C + PixelShuffle) (Restormer.py:171-189) through the
+    native im2col / col2im GEMM forms and the native pixel (un)shuffle, against torch in fp64: output, input and weight grads."""
+    import torch.nn.functional as F
+    m = M()
+    torch.manual_seed(11)
+    mod = (m.Downsample(c) if kind == "down" else m.Upsample(c))
+    H, W = hw
+    x = seeded_input((2, c, H, W), 960)
+    wr = mod.body[0].weight.detach().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr = F.pixel_unshuffle(yr, 2) if kind == "down" else F.pixel_shuffle(yr, 2)
+    cot = seeded_input(tuple(yr.shape), 961)
+    yr.backward(cot.double())
+    mod = mod.to(DEV)
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    y = mod(xg)
+    assert "PixelShuffle" in type(y.grad_fn).__name__, "native pixel (un)shuffle not taken"
+    y.backward(cot.to(DEV).to(dtype))
+    assert rel(y, yr) < tol and rel(xg.grad, xr.grad) < tol and rel(mod.body[0].weight.grad, wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_up_cat_writes_into_concat_buffer(dtype):
+    """cat([PixelShuffle(z), skip]) without the intermediate (decoder level 1, Restormer.py:265-266): exact data movement."""
+    import torch.nn.functional as F
+    from image_restoration_amd import restormer as RM
+    z = seeded_input((2, 64, 8, 16), 970).to(DEV).to(dtype).requires_grad_(True)
+    skip = seeded_input((2, 16, 16, 32), 971).to(DEV).to(dtype).requires_grad_(True)
+    out = RM._UpCatFn.apply(z, skip)
+    ref = torch.cat([F.pixel_shuffle(z.detach(), 2), skip.detach()], 1)
+    assert torch.equal(out, ref)
+    cot = seeded_input(tuple(out.shape), 972).to(DEV).to(dtype)
+    out.backward(cot)
+    assert torch.equal(z.grad, F.pixel_unshuffle(cot[:, :16], 2)) and torch.equal(skip.grad, cot[:, 16:])
