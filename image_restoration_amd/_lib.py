@@ -149,6 +149,9 @@ SIGNATURES = {
     "mi_ewise_bwd": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_i64, c_i64, C.c_int, C.c_int, vp]),
     "mi_pixel_shuffle2": (C.c_int, [vp, c_i64, vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_copy_rows": (C.c_int, [vp, c_i64, vp, c_i64, c_i64, c_i64, C.c_int, vp]),
+    "mi_patch_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, fp, fp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_psnr_ssim_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_psnr_ssim": (C.c_int, [vp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "mi_gap_fwd": (C.c_int, [vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_gap_bwd": (C.c_int, [fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
     "mi_cast": (C.c_int, [vp, C.c_int, vp, C.c_int, c_i64, vp]),

@@ -1,0 +1,55 @@
+"""Full-image tiled inference (BASELINE configs[4]).
+
+The reference's test loops push the whole image through the network (MoCE-IR-main/src/test.py:82-123, after cropping it to a
+multiple of the base size, src/utils/image_utils.py:62-67); its tiling helpers (image_utils.py:71-101) are never called by a
+harness, so the tiling below is this build's own definition:
+
+  * the image is cut into ``tile`` x ``tile`` output cells; each cell is restored from the cell plus ``overlap`` pixels of
+    context on every side (replicated at the image border, like the reference helper's ``np.pad(mode='edge')``), i.e. the
+    network sees (tile + 2 overlap)^2 inputs and only the central tile^2 outputs are kept;
+  * the cells of an image are independent network evaluations: they are batched ``tile_batch`` at a time through the
+    no_grad path (fused LN + GDFN kernel, nothing saved for backward);
+  * MDTA statistics (L2 norms over all pixels, C x C attention) are global over whatever the network sees, so tiled output
+    is NOT the full-image output; parity for this configuration is tile-versus-tile (tests/test_gpu_inference.py).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def crop_to_multiple(img: torch.Tensor, base: int = 16) -> torch.Tensor:
+    """image_utils.crop_img on a [B,C,H,W] tensor."""
+    h, w = img.shape[-2:]
+    ch, cw = h % base, w % base
+    return img[..., ch // 2:h - ch + ch // 2, cw // 2:w - cw + cw // 2]
+
+
+@torch.no_grad()
+def tiled_restore(model, img: torch.Tensor, tile: int = 224, overlap: int = 16, tile_batch: int = 8,
+                  dtype: Optional[torch.dtype] = torch.bfloat16) -> torch.Tensor:
+    """img [B,3,H,W] in [0,1] -> restored [B,3,H,W] (same dtype as ``img``).  The default 224 + 2 x 16 gives 256 x 256
+    network inputs: every level then has power-of-two rows (256 / 128 / 64 / 32), which is what the streaming depthwise, the
+    native 3x3 glue and the fused LN + GDFN kernels are built for.  H, W need not be multiples of ``tile``: the image is
+    edge-replicated up to the cell grid and the result cropped back."""
+    B, C, H0, W0 = img.shape
+    x = img.to(dtype) if dtype is not None else img
+    H, W = -(-H0 // tile) * tile, -(-W0 // tile) * tile
+    xp = F.pad(x, (overlap, overlap + W - W0, overlap, overlap + H - H0), mode="replicate")
+    size = tile + 2 * overlap
+    cells = [(b, i, j) for b in range(B) for i in range(H // tile) for j in range(W // tile)]
+    out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+    was_training = model.training
+    model.eval()
+    try:
+        for s in range(0, len(cells), tile_batch):
+            chunk = cells[s:s + tile_batch]
+            batch = torch.stack([xp[b, :, i * tile:i * tile + size, j * tile:j * tile + size] for b, i, j in chunk]).contiguous()
+            y = model(batch)
+            for k, (b, i, j) in enumerate(chunk):
+                out[b, :, i * tile:(i + 1) * tile, j * tile:(j + 1) * tile] = y[k, :, overlap:overlap + tile, overlap:overlap + tile]
+    finally:
+        model.train(was_training)
+    return out[:, :, :H0, :W0].to(img.dtype)

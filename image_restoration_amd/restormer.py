@@ -14,6 +14,7 @@ in place and reports no autograd gradient for the parameters; otherwise ordinary
 from __future__ import annotations
 
 import numbers
+import os
 import threading
 from typing import List, Optional, Sequence
 
@@ -193,7 +194,7 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
     xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
     y, _ = ops.mdta_fwd(xn, x, att, block.attn.num_heads, False)
     hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
-    if ops.gdfn_fused_ok(y, hidden, ks):
+    if ops.gdfn_fused_ok(y, hidden, ks) and not os.environ.get("MI_NO_FUSED_INFER"):      # (A/B switch)
         pack = _fused_gdfn_pack(block, y, n2, ffn)
         out, _, _ = ops.gdfn_fused_fwd(y, pack, hidden, wb, want_stats=False)
         return out

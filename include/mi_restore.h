@@ -348,6 +348,30 @@ int mi_copy_rows(const void* src, int64_t src_rs, void* dst, int64_t dst_rs, int
 int mi_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtype, void* stream);
 int mi_gap_bwd(const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Training samples on the device (MoCE-IR-main/src/data/dataset_utils.py:156-165 AIOTrainDataset.__getitem__, denoise tasks;
+ * src/data/degradation_utils.py:21-24; src/utils/image_utils.py data_augmentation): for sample b of the batch
+ *   patch = image[sample[b]][top[b] : top[b]+P, left[b] : left[b]+P]      (decoded uint8 HWC images in one flat `pool`,
+ *                                                                           image s at pool + src_off[s], src_h[s] x src_w[s])
+ *   aug   = data_augmentation(patch, mode[b])                              (the 8 dihedral modes, numbered as the reference)
+ *   clean[b]    = aug / 255                                                 (CHW, activation dtype)
+ *   degraded[b] = uint8(clip(aug + sigma[b] * noise[b], 0, 255)) / 255      (noise: the caller's N(0,1) draw, [B,3,P,P])
+ * clean or degraded may be NULL.  The caller keeps top/left inside the image.
+ * ------------------------------------------------------------------------ */
+int mi_patch_batch(const unsigned char* pool, const int64_t* src_off, const int* src_h, const int* src_w, const int* sample,
+                   const int* top, const int* left, const int* mode, const float* sigma, const float* noise, void* clean,
+                   void* degraded, int B, int P, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Evaluation metrics as the reference's test loops compute them through scikit-image (AdaIR-main/utils/val_utils.py:50-64;
+ * MoCE-IR-main/src/test.py:82-123): inputs clipped to [0,1];  psnr[b] = 10 log10(1 / MSE);  ssim[b] = structural_similarity
+ * with data_range 1, 7x7 uniform window, K1 0.01, K2 0.03, sample covariance, 3-pixel border excluded, channel mean.
+ * ws: mi_psnr_ssim_workspace() bytes.  Deterministic (fixed-order sums).
+ * ------------------------------------------------------------------------ */
+size_t mi_psnr_ssim_workspace(int B, int C, int H, int W);
+int mi_psnr_ssim(const void* restored, const void* clean, float* psnr, float* ssim, int B, int C, int H, int W, int dtype,
+                 void* ws, void* stream);
+
 /* dtype conversion / L1 loss helpers used by the harness */
 int mi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* loss[0] += mean|a-b| ; da = sign(a-b) * scale (da may be NULL); loss must hold 1+1024 floats

@@ -22,7 +22,7 @@ Tensor = torch.Tensor
 __all__ = [
     "layernorm_nchw", "gdfn", "mdta", "mdta_cross", "transformer_block",
     "restormer_forward", "restormer_config", "RESTORMER_BASE", "RESTORMER_TINY",
-    "make_restormer_state", "psnr", "degrade_sigma", "sub_state",
+    "make_restormer_state", "psnr", "ssim", "degrade_sigma", "sub_state",
 ]
 
 LN_EPS = 1e-5          # Restormer.py:39,57  (eps sits INSIDE the sqrt)
@@ -324,3 +324,27 @@ def psnr(restored: Tensor, clean: Tensor) -> float:
     c = clean.detach().double().clamp(0, 1)
     mse = ((r - c) ** 2).mean().item()
     return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+def ssim(restored: Tensor, clean: Tensor) -> float:
+    """Mean SSIM over a batch as scikit-image's ``structural_similarity(clean, restored, data_range=1, multichannel=True)``
+    computes it for float images (the metric AdaIR-main/utils/val_utils.py:50-64 calls; scikit-image is a third-party
+    dependency that is NOT installed here - pinned in the upstream requirements as scikit-image 0.19-0.21 - so this is a
+    restatement of its published algorithm, Wang et al. 2004 with the library's defaults, and is PARITY UNPINNED):
+    7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance (N / (N - 1)), SSIM map averaged over the pixels whose window
+    lies inside the image (3-pixel border dropped) and over the channels; inputs clipped to [0, 1] first."""
+    x = restored.detach().double().clamp(0, 1)
+    y = clean.detach().double().clamp(0, 1)
+    k = torch.ones(1, 1, 7, 7, dtype=torch.float64) / 49.0
+    B, C, H, W = x.shape
+
+    def box(t):
+        return F.conv2d(t.reshape(B * C, 1, H, W), k)           # 'valid' = the cropped interior
+    ux, uy = box(x), box(y)
+    cn = 49.0 / 48.0
+    vx = cn * (box(x * x) - ux * ux)
+    vy = cn * (box(y * y) - uy * uy)
+    vxy = cn * (box(x * y) - ux * uy)
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return float(s.mean())
