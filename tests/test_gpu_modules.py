@@ -341,3 +341,31 @@ def test_up_cat_writes_into_concat_buffer(dtype):
     cot = seeded_input(tuple(out.shape), 972).to(DEV).to(dtype)
     out.backward(cot)
     assert torch.equal(z.grad, F.pixel_unshuffle(cot[:, :16], 2)) and torch.equal(skip.grad, cot[:, 16:])
+
+
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 32, 64)), (96, 2, (1, 96, 16, 32))])
+def test_block_fp32_elementwise_relative(c, heads, shape):
+    """Every other bound in this file is max|delta| / max|ref| (one scale per tensor).  Here the fp32 path is also held to an
+    ELEMENT-WISE bound against the fp64 oracle - |delta_i| <= 1e-3 |ref_i| + 1e-5 max|ref| for every element of the output, the
+    input gradient and every parameter gradient - which is the literal reading of north_star's "1e-3 relative fp32"."""
+    m = M()
+    sd = R.make_block_state(c, heads, 2.66, True, "WithBias", seed=5 + c)
+    blk = m.TransformerBlock(c, heads, 2.66, True, "WithBias")
+    blk.load_state_dict(sd)
+    x, cot = seeded_input(shape, 6100 + c), seeded_input(shape, 6101 + c)
+    y, dx, g = run(blk, x, cot)
+    xr = x.double().requires_grad_(True)
+    ps = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    yr = R.transformer_block(xr, ps, heads, "WithBias")
+    yr.backward(cot.double())
+
+    def elementwise(got, ref, what):
+        ref = ref.detach().double()
+        d = (got.detach().cpu().double() - ref).abs()
+        bound = 1e-3 * ref.abs() + 1e-5 * ref.abs().max()
+        bad = int((d > bound).sum())
+        assert bad == 0, f"{what}: {bad} of {d.numel()} elements outside 1e-3 relative (+1e-5 of the tensor's max); worst {float((d / bound).max()):.2f}x"
+    elementwise(y, yr, "y")
+    elementwise(dx, xr.grad, "dx")
+    for k, v in g.items():
+        elementwise(v, ps[k].grad, "g_" + k)
