@@ -67,7 +67,7 @@ class XmdtaGrads(C.Structure):
 
 class GdfnShape(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("dtype", C.c_int), ("ks", C.c_int)]
+                ("dtype", C.c_int), ("ks", C.c_int), ("flags", C.c_int)]
 
 
 class GdfnParams(C.Structure):

@@ -281,7 +281,9 @@ static int xmdta_check(const mi_xmdta_shape* s) {
 // stored y; the recomputing backward needed packed-fp32 math for that (975 us without: VALU-bound).
 struct GdfnSaved { void* h0; void* h1; void* g; size_t bytes; };
 static bool gdfn_recompute(const mi_gdfn_shape* s) {
-  return !getenv("MI_GDFN_STORE_Y") && mi_dwconv_gate_recompute_ok(s->H, s->W, s->ks) != 0;
+  // the layout switch travels in the shape (flags bit 0), never in the environment: forward and backward of one call pair
+  // must carve the saved blob identically
+  return !(s->flags & 1) && mi_dwconv_gate_recompute_ok(s->H, s->W, s->ks) != 0;
 }
 static GdfnSaved gdfn_saved_layout(const mi_gdfn_shape* s, void* base) {
   const size_t N = (size_t)s->H * s->W, B = s->B, h = s->hidden;

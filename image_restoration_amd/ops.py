@@ -7,6 +7,7 @@ All compute happens in ``libmi_restore.so``.  CPU tensors are rejected: there is
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -287,9 +288,9 @@ def xmdta_bwd(x: Tensor, y: Tensor, dout: Tensor, params: Sequence[Optional[Tens
     return dx, dy
 
 
-def _gdfn_shape(x: Tensor, hidden: int, ks: int) -> L.GdfnShape:
+def _gdfn_shape(x: Tensor, hidden: int, ks: int, flags: int = 0) -> L.GdfnShape:
     B, Cc, H, W = x.shape
-    return L.GdfnShape(B, Cc, hidden, H, W, _dt(x), ks)
+    return L.GdfnShape(B, Cc, hidden, H, W, _dt(x), ks, flags)
 
 
 def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool):
@@ -298,7 +299,9 @@ def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_sa
     for t in params:
         _f32(t, "GDFN parameter")
     hidden, ks = params[4].shape[1], params[2].shape[-1]
-    s = _gdfn_shape(x, hidden, ks)
+    # A/B switch: keep the conv output instead of recomputing it in backward.  Read here, once per forward; backward
+    # recovers the choice from the blob's size, so toggling the variable between the two cannot desynchronise them.
+    s = _gdfn_shape(x, hidden, ks, 1 if os.environ.get("MI_GDFN_STORE_Y") else 0)
     lib = L.lib()
     out = torch.empty_like(x)
     saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(s)), x.device) if need_saved else None
@@ -313,8 +316,15 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
              accumulate: bool) -> Tensor:
     _gpu(x, dout, saved, *params, *grads)
     hidden, ks = params[4].shape[1], params[2].shape[-1]
-    s = _gdfn_shape(x, hidden, ks)
     lib = L.lib()
+    s = None
+    for flags in (0, 1):                   # which layout did the forward carve?  the two differ in size
+        cand = _gdfn_shape(x, hidden, ks, flags)
+        if max(int(lib.mi_gdfn_saved_bytes(C.byref(cand))), 256) == saved.numel():
+            s = cand
+            break
+    if s is None:
+        raise RuntimeError("gdfn_bwd: the saved blob matches neither layout of this shape")
     dx = torch.empty_like(x)
     ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
     pp = L.GdfnParams(*[_p(t) for t in params])

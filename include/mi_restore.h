@@ -207,7 +207,9 @@ int mi_xmdta_bwd(const mi_xmdta_shape* s, const mi_xmdta_params* p, const void* 
  * GDFN — FeedForward.forward / backward (Restormer.py:76-93; moce_ir.py:255-276;
  * AdaIR-main/net/model.py:76-94).  hidden = h (project_in has 2h outputs).
  * ------------------------------------------------------------------------ */
-typedef struct { int B, C, hidden, H, W, dtype, ks; } mi_gdfn_shape;
+/* flags bit 0: the forward also stores the depthwise conv's output for backward (no recompute; chosen by the caller and
+ * passed unchanged to mi_gdfn_saved_bytes / _fwd / _bwd of one forward-backward pair: it fixes the saved blob's layout) */
+typedef struct { int B, C, hidden, H, W, dtype, ks, flags; } mi_gdfn_shape;
 typedef struct {
   const float* in_w;  const float* in_b;   /* [2h,C], [2h]|NULL */
   const float* dw_w;  const float* dw_b;   /* [2h,ks*ks], [2h]|NULL */

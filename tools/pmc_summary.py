@@ -20,3 +20,7 @@ for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
         print(f"   insts/wave: VALU {c['SQ_INSTS_VALU']/w2:.0f} LDS {c.get('SQ_INSTS_LDS',0)/w2:.0f} VMEM_RD {c.get('SQ_INSTS_VMEM_RD',0)/w2:.0f} "
               f"VMEM_WR {c.get('SQ_INSTS_VMEM_WR',0)/w2:.0f} SALU {c.get('SQ_INSTS_SALU',0)/w2:.0f}  bank-conflict/LDS-active "
               f"{100*c.get('SQ_LDS_BANK_CONFLICT',0)/max(c.get('SQ_LDS_IDX_ACTIVE',1),1):.0f}%  WAIT_INST_LDS {100*c.get('SQ_WAIT_INST_LDS',0)/wc:.1f}%")
+    if "SQ_INSTS_MFMA" in c:
+        w3 = c.get("SQ_WAVES", waves)
+        print(f"   MFMA/wave {c['SQ_INSTS_MFMA']/w3:.0f}  MFMA busy cycles / wave-quad-cycles {100*c.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/(4*wc):.1f}%  "
+              f"TRANS/wave {c.get('SQ_INSTS_VALU_TRANS',0)/w3:.0f}  VMEM inst cycles {100*c.get('SQ_INST_CYCLES_VMEM',0)/wc:.1f}%")
