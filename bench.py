@@ -24,8 +24,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   fp32_line        : a short run of the same step with fp32 activations (the exact-MFMA parity path, the reference's
                      mainline precision), reported beside the bf16 headline, never instead of it;
   cpu_baseline     : the CPU oracle (oracle/restormer_ref.py, "port") timed on this box's host cores: warm-up + median of
-                     3, forward and forward+backward, at all cores and at 8 threads, on a 128x128 patch so that the whole
-                     leg stays within ~30 s (rank 0 at N=1 only).
+                     3, forward and forward+backward, at all cores, 16 and 8 threads (value = the fastest), on a 128x128 patch: the
+                     whole leg stays within ~40 s (rank 0 at N=1 only).
 """
 from __future__ import annotations
 
@@ -110,7 +110,7 @@ def pmc_traffic(kernel: str):
 
 
 def cpu_baseline(patch: int = 128):
-    """Oracle training step on one patch, fp32: warm-up + median of 3, forward and forward+backward, all cores and 8 threads."""
+    """Oracle training step on one patch, fp32: warm-up + median of 3, forward and forward+backward, all cores, 16 and 8 threads; value = the fastest."""
     from image_restoration_amd.configs import RESTORMER_BASE as cfg
     from oracle import restormer_ref as R
     sd = {k: v.requires_grad_(True) for k, v in R.make_restormer_state(cfg, seed=0).items()}
@@ -138,11 +138,13 @@ def cpu_baseline(patch: int = 128):
     allc = min(os.cpu_count() or 1, 64)
     res = {}
     t_start = time.perf_counter()
-    for threads in sorted({allc, 8}, reverse=True):
+    for threads in sorted({allc, 16, 8}, reverse=True):
         torch.set_num_threads(threads)
         res[threads] = {"fwd_s": med(fwd), "train_s": med(train)}
     px = patch * patch / 1e6
-    return {"value": round(px / res[allc]["train_s"], 6), "unit": "Mpixels/s", "cores": allc, "kind": "port",
+    # value = the best thread setting (a box's GPU share of host cores is below os.cpu_count(): oversubscribed runs are slower)
+    best = min(res, key=lambda t: res[t]["train_s"])
+    return {"value": round(px / res[best]["train_s"], 6), "unit": "Mpixels/s", "cores": best, "kind": "port",
             "sample": f"oracle.restormer_forward (+ L1 + backward), 1x3x{patch}x{patch} fp32, warm-up + median of 3; "
                       f"whole leg {time.perf_counter() - t_start:.1f} s",
             "train_mpix_s": {str(t): round(px / r["train_s"], 6) for t, r in res.items()},
