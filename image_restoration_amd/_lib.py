@@ -79,6 +79,10 @@ class GdfnFusedShape(C.Structure):
                 ("ln_with_bias", C.c_int)]
 
 
+class LnTail(C.Structure):
+    _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("dres", vp), ("dw", fp), ("db", fp)]
+
+
 class GdfnGrads(C.Structure):
     _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp),
                 ("accumulate", C.c_int)]
@@ -121,6 +125,18 @@ SIGNATURES = {
                                vp, vp]),
     "mi_gdfn_saved_bytes": (C.c_size_t, [C.POINTER(GdfnShape)]),
     "mi_gdfn_workspace": (C.c_size_t, [C.POINTER(GdfnShape)]),
+    "mi_bwd_tail_ok": (C.c_int, [C.c_int, C.c_int, c_i64, C.c_int]),
+    "mi_bwd_tail_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "mi_bwd_tail": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, fp, fp, fp, fp, fp, vp, fp, fp, fp, C.c_int, c_i64, C.c_int,
+                              C.c_int, vp, vp]),
+    "mi_mdta_bwd_ln_ok": (C.c_int, [C.POINTER(MdtaShape), C.c_int]),
+    "mi_mdta_bwd_ln_workspace": (C.c_size_t, [C.POINTER(MdtaShape)]),
+    "mi_mdta_bwd_ln": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnTail), vp, vp, vp,
+                                 C.POINTER(MdtaGrads), vp, vp, vp]),
+    "mi_gdfn_bwd_ln_ok": (C.c_int, [C.POINTER(GdfnShape), C.c_int]),
+    "mi_gdfn_bwd_ln_workspace": (C.c_size_t, [C.POINTER(GdfnShape)]),
+    "mi_gdfn_bwd_ln": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnTail), vp, vp, vp,
+                                 C.POINTER(GdfnGrads), vp, vp, vp]),
     "mi_gdfn_fwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, vp, vp, vp]),
     "mi_gdfn_bwd": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), vp, vp, vp, C.POINTER(GdfnGrads), vp, vp,
                               vp]),

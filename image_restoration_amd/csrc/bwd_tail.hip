@@ -1,0 +1,513 @@
+// Backward tail of a half-block in one launch.
+//
+// A Restormer half-block is  out = x + F(LN(x))  with F starting in a 1x1 conv  h = W LN(x)  (qkv, Restormer.py:105,115;
+// project_in, Restormer.py:82,89; LN = WithBias_LayerNorm, Restormer.py:52-64).  Given dY = dL/dh the backward still owes
+//     dW  = dY LN(x)^T                       (weight gradient,  [M, C], summed over batch and pixels)
+//     dxn = W^T dY                           (input gradient of the conv)
+//     dx  = LNbackward(dxn; x, mean, rstd) + dres      (dres = gradient arriving over the residual connection)
+//     dgamma, dbeta                          (LayerNorm parameter gradients)
+// The unfused chain runs a Gram kernel, a GEMM and the LayerNorm backward: dY is streamed twice, dxn written and read, LN(x)
+// stored by the forward and read here - (2M + 6C) planes of traffic per pixel.  This kernel streams dY, x and dres once and
+// writes dx: (M + 3C) planes, and LN(x) no longer has to be saved by the forward.
+//
+// With xh = (x - mean) rstd (no affine):  LN(x) = gamma xh + beta, so with  G = dY xh^T  and  S = rowsum(dY):
+//     dW[m,c] = gamma_c G[m,c] + beta_c S[m],    dgamma_c = sum_m W[m,c] G[m,c],    dbeta_c = sum_m W[m,c] S[m]
+// (dgamma_c = sum_p dxn[c,p] xh[c,p] with dxn = W^T dY).  The streaming kernel therefore only accumulates G and S; a tiny
+// finishing kernel turns them into the three parameter gradients.
+//
+// Work split: a workgroup owns 64-pixel tiles (persistent loop), wave w owns dY rows [16 MPW w, 16 MPW (w+1)):
+//   * G: the wave's rows x all C columns stay in its accumulators for the whole kernel (MFMA, contraction over pixels);
+//   * dxn: each wave contracts over ITS rows only (W^T fragments in registers, dY transposed by ds_read_b64_tr_b16 from the
+//     wave-private patch) and adds its partial tile into a shared fp32 LDS accumulator with ds_add_f32;
+//   * after a barrier all lanes run the LayerNorm backward on the accumulator (8 or 4 lanes per pixel), transpose the result
+//     through LDS and store 128-byte rows of dx.
+// The next tile's dY rows, x, dres and statistics are in flight (registers) while a tile is computed.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "internal.h"
+#include "fused_common.h"
+
+namespace mi {
+namespace {
+using namespace fz;
+
+constexpr int BT_PS = 72;   // bf16 row stride of every 64-pixel LDS tile (64 + pad: conflict-free 8-byte and transposed reads)
+
+struct BtArgs {
+  const bf16* dy;      // [B][M][N]
+  const bf16* x;       // [B][C][N]   LayerNorm input
+  const bf16* dres;    // [B][C][N]   or null
+  const float* mean;   // [B][N]
+  const float* rstd;   // [B][N]
+  const float* w;      // [M][C]
+  const float* gamma;  // [C]
+  bf16* dx;            // [B][C][N]
+  float* gpart;        // [grid][M][C]
+  float* spart;        // [grid][mpad]
+  int M, mpad;
+  int64_t N;
+  int tiles_per_image;
+  int ntiles;
+  int dbg;             // MI_BT_DEBUG ablation mask (timing only: results are wrong when set)
+};
+
+template <int C_, int NW_, int MPW_>
+struct BtCfg {
+  static constexpr int C = C_, NW = NW_, MPW = MPW_;
+  static constexpr int CT = C / 16;
+  static constexpr int ROWS = 16 * MPW;          // dY rows of one wave
+  static constexpr int KS = (ROWS + 31) / 32;    // 32-deep steps of the dxn contraction over those rows
+  static constexpr int PROWS = 32 * KS;          // patch rows (rows past ROWS stay zero)
+  static constexpr int NT = 64 * NW;
+  static constexpr int XS = 68;                  // fp32 stride of the dxn accumulator [channel][64 pixels + pad]
+  static constexpr int TPS = 4 * (C / 16) / NW;  // 16 x 16 output fragments per slice of the rotating reduction
+  static constexpr int LPP = NT / 64;            // lanes per pixel in the LayerNorm-backward phase
+  static constexpr int CPL = C / LPP;            // channels per lane there
+  static constexpr int ITEMS = C * 16 / NT;      // (channel row, 4-pixel quad) items per lane when dx is stored
+  static constexpr int XP = C / 8;               // 1 KiB LDS-DMA pieces (8 rows x 64 px) of the x tile; as many of dres
+  static constexpr int PPW = 2 * XP / NW;        // pieces per wave
+  static constexpr int PATCH_E = PROWS * BT_PS;
+  static constexpr int TILE_B = C * 128;         // bytes of one unpadded, chunk-swizzled [C][64] bf16 tile
+  static constexpr int OFF_XH = NW * PATCH_E * 2;
+  static constexpr int OFF_DR = OFF_XH + 2 * TILE_B;
+  static constexpr int OFF_ACC = OFF_DR + 2 * TILE_B;
+  static constexpr int OFF_GAM = OFF_ACC + C * XS * 4;
+  static constexpr int OFF_ST = OFF_GAM + C * 4;
+  static constexpr int BYTES = OFF_ST + NW * 512;
+  static_assert(C % 16 == 0 && (LPP == 4 || LPP == 8) && C % LPP == 0 && (C * 16) % NT == 0 && (2 * XP) % NW == 0,
+                "unsupported shape");
+  static_assert((NW == 8 && C == 96) || (NW == 4 && C == 48), "slice map of the rotating reduction: 3 fragments per slice");
+  static_assert(BYTES <= 160 * 1024, "LDS budget");
+};
+
+// element index of (channel c, pixel px) in an unpadded [C][64] bf16 tile whose 16-byte chunks are XOR-swizzled by the row:
+// 128-byte rows would put every row on the same banks; with chunk position (px/8) ^ ((c/2) & 7) the 8-byte operand reads of 16
+// consecutive rows, the 2-byte reads of the LayerNorm phase and the row-wise store all spread over the banks, and the tile can
+// be filled by LDS-DMA (which writes a wave's 1 KiB linearly) by permuting the SOURCE chunks instead.
+__device__ __forceinline__ int bt_swz(int c, int px) { return c * 64 + ((((px >> 3) ^ (c >> 1)) & 7) << 3) + (px & 7); }
+
+template <int C, int NW, int MPW>
+__global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2 : 1)) void bt_kernel(BtArgs a) {
+  using K = BtCfg<C, NW, MPW>;
+  constexpr int CT = K::CT, KS = K::KS, PS = BT_PS, XS = K::XS, NT = K::NT, LPP = K::LPP, CPL = K::CPL, ITEMS = K::ITEMS;
+  constexpr int XP = K::XP, PPW = K::PPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+  bf16* const patch = reinterpret_cast<bf16*>(lds) + wv * K::PATCH_E;
+  float* const acc = reinterpret_cast<float*>(lds + K::OFF_ACC);
+  float* const st = reinterpret_cast<float*>(lds + K::OFF_ST + wv * 512);   // this wave's copy of mean[64], rstd[64]
+  const int m0 = wv * K::ROWS;
+  const bool active = m0 < a.M;                                         // wave-uniform
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const unsigned un = (unsigned)a.N;
+
+  for (int i = lane; i < K::PATCH_E / 8; i += 64) reinterpret_cast<u32x4*>(patch)[i] = zero4;
+
+  // (W diag(gamma))^T fragments (B operand of the dxn product): column c = 16 ct + li, k slots = this wave's rows in the
+  // patch's slot order
+  s16x8 wt[CT][KS];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ml = 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4), m = m0 + ml;
+        const int mc = (ml < K::ROWS && m < a.M) ? m : 0;
+        const float v = a.w[mc * C + 16 * ct + li] * a.gamma[16 * ct + li];     // gamma folded in: the product is g = gamma dxn
+        wt[ct][ks][j] = (ml < K::ROWS && m < a.M) ? bf_bits(v) : (short)0;
+      }
+  f32x4 G[MPW][CT];
+  float S[MPW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    S[i] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) G[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // dY rows travel through registers in two 32-pixel halves: while one half is computed the next is in flight.
+  // x, dres and the statistics of the NEXT tile go straight to LDS (global_load_lds), no registers involved.
+  u32x4 R[MPW];
+  const int rl = lane >> 2;                                            // row inside a 16-row fragment, 64 bytes (4 lanes) per row
+  auto issue_dy = [&](int tile, int h) {
+    const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64 + 32 * h;
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      const int lim = a.M - 1 - (m0 + 16 * j);                          // last valid row of this fragment (wave-uniform)
+      if (lim >= 0) {
+        const bf16* base = a.dy + ((int64_t)b * a.M + m0 + 16 * j) * a.N + p0;
+        const unsigned off = (unsigned)(rl < lim ? rl : lim) * un + 8u * (lane & 3);
+        R[j] = *reinterpret_cast<const u32x4*>(base + off);
+      }
+    }
+  };
+  auto stage_dy = [&](int h) {
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      const int lim = a.M - 1 - (m0 + 16 * j);
+      *reinterpret_cast<u32x4*>(&patch[(16 * j + rl) * PS + 32 * h + 8 * (lane & 3)]) = rl <= lim ? R[j] : zero4;
+    }
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue_x = [&](int tile, int nb) {
+    const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64;
+    const int64_t img = (int64_t)b * C * a.N + p0;
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int pid = wv + NW * k;                                      // wave-uniform
+      const bool isx = pid < XP;
+      const int u = isx ? pid : pid - XP, c = 8 * u + (lane >> 3), kk = ((lane & 7) ^ (c >> 1)) & 7;
+      if (isx || a.dres) {
+        const bf16* src = (isx ? a.x : a.dres) + img + (unsigned)c * un + 8u * kk;
+        unsigned char* dst = lds + (isx ? K::OFF_XH : K::OFF_DR) + nb * K::TILE_B + u * 1024;
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)dst, 16, 0, 0);
+      }
+    }
+    const int64_t so = (int64_t)b * a.N + p0 + lane;
+    __builtin_amdgcn_global_load_lds((const void*)(a.mean + so), (lds_ptr)(lds + K::OFF_ST + wv * 512), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)(a.rstd + so), (lds_ptr)(lds + K::OFF_ST + wv * 512 + 256), 4, 0, 0);
+  };
+  // One 32-pixel half of the weight-gradient work: G += dY xh^T (and the row sums S).  Lane coordinates are re-derived from an
+  // opaque copy of the lane id: every LDS address below is loop-invariant, and hoisting the few dozen of them out of the tile
+  // loop is what pushes the kernel over its register budget.
+  auto wgrad_half = [&](int h, const bf16* xh) {
+    if (a.dbg & 1) return;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int li_ = ln & 15, g_ = ln >> 4;
+    constexpr int GRP = MPW;                                             // row fragments held at once
+    const bf16* ar0 = &patch[li_ * PS + 32 * h + 4 * g_];
+    // swizzled chunk of pixel 32h + 16e + 4g in row 16ct + li: the row term (li/2) does not depend on ct
+    const int f = (li_ >> 1) & 7, k0 = 4 * h + (g_ >> 1);
+    const bf16* b_lo = xh + li_ * 64 + ((k0 ^ f) << 3) + 4 * (g_ & 1);
+    const bf16* b_hi = xh + li_ * 64 + (((k0 + 2) ^ f) << 3) + 4 * (g_ & 1);
+#pragma unroll
+    for (int i0 = 0; i0 < MPW; i0 += GRP) {
+      s16x8 A[GRP];
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+        const bf16* ar = ar0 + 16 * (i0 + i) * PS;
+        A[i] = cat8(*reinterpret_cast<const s16x4*>(ar), *reinterpret_cast<const s16x4*>(ar + 16));
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm += bf_s(A[i][j]);
+        S[i0 + i] += sm;
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const s16x8 Bx = cat8(*reinterpret_cast<const s16x4*>(b_lo + ct * 16 * 64), *reinterpret_cast<const s16x4*>(b_hi + ct * 16 * 64));
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) G[i0 + i][ct] = mfma32(A[i], Bx, G[i0 + i][ct]);
+      }
+    }
+  };
+  // dxn = W^T dY needs the sum over ALL rows, i.e. over the waves.  (ds_add_f32 into a shared tile measured ~190 cycles per
+  // wave-instruction on gfx950 - lane-serialised - and made the kernel 8x slower than everything else in it.)  Instead the
+  // 64 x C output tile is cut into NW slices of three 16 x 16 fragments; in step s wave w owns slice (w + s) mod NW: it loads
+  // the running sum as the MFMA accumulator input (step 0: zero), adds its rows' contribution and stores it back.  A barrier
+  // separates steps.
+  auto dxn_step = [&](auto sc, const bf16* xh) {
+    constexpr int s = decltype(sc)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int li_ = ln & 15, g_ = ln >> 4, qq_ = li_ >> 2, pp_ = li_ & 3;
+    const int j = (wv + s) & (NW - 1);                                  // wave-uniform
+    const int nt = NW == 8 ? (j >> 1) : j;
+    const bool skip = (a.dbg & 2) != 0;
+    const bf16* tr0 = &patch[(4 * g_ + qq_) * PS + 16 * nt + 4 * pp_];
+    s16x4 lo[KS], hi[KS];
+    if (!skip) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        lo[ks] = tr_b16(tr0 + (32 * ks) * PS);
+        hi[ks] = tr_b16(tr0 + (32 * ks + 16) * PS);
+      }
+    }
+    float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];   // 4 consecutive pixels of one channel
+    f32x4 d[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) d[u] = s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ap0 + 16 * u * XS);
+    if (skip) return;
+    if (KS == 1) lds_wait(lo[0], hi[0]);
+    else lds_wait(lo[0], hi[0], lo[KS - 1], hi[KS - 1]);
+    auto run = [&](auto ct0) {
+      constexpr int CT0 = decltype(ct0)::value;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) d[u] = mfma32(cat8(lo[ks], hi[ks]), wt[CT0 + u][ks], d[u]);
+        *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = d[u];
+      }
+    };
+    if (NW == 8 && (j & 1)) run(std::integral_constant<int, (CT > 3 ? 3 : 0)>{});
+    else run(std::integral_constant<int, 0>{});
+  };
+  // a wave without rows owns a slice in step 0 all the same: it stores the zeros the others then add to
+  auto dxn_zero = [&]() {
+    const int j = wv, nt = NW == 8 ? (j >> 1) : j, li_ = lane & 15, g_ = lane >> 4;
+    float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto for_steps = [&](auto self, auto sc, const bf16* xh) -> void {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s < NW) {
+      if (active && !(a.dbg & 32)) dxn_step(sc, xh);
+      else if (s == 0) dxn_zero();
+      __syncthreads();
+      self(self, std::integral_constant<int, s + 1>{}, xh);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    if (active) issue_dy(tile, 0);
+    issue_x(tile, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+    const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64;
+    const int nxt = tile + gridDim.x;
+    bf16* const xh = reinterpret_cast<bf16*>(lds + K::OFF_XH + buf * K::TILE_B);
+    bf16* const dr = reinterpret_cast<bf16*>(lds + K::OFF_DR + buf * K::TILE_B);
+    // ---- this wave's DMA pieces and dY half have landed: dY -> patch, x -> xh = (x - mean) rstd in place
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (active) stage_dy(0);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int pid = wv + NW * k;
+      if (pid < XP) {
+        const int c = 8 * pid + (lane >> 3), kk = ((lane & 7) ^ (c >> 1)) & 7;
+        u32x4* slot = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(xh) + pid * 1024 + lane * 16);
+        const u32x4 v = *slot;
+        const f32x4 m_lo = *reinterpret_cast<const f32x4*>(&st[8 * kk]), m_hi = *reinterpret_cast<const f32x4*>(&st[8 * kk + 4]);
+        const f32x4 r_lo = *reinterpret_cast<const f32x4*>(&st[64 + 8 * kk]), r_hi = *reinterpret_cast<const f32x4*>(&st[64 + 8 * kk + 4]);
+        u32x4 o;
+        o[0] = pack_bf2((bf_lo(v[0]) - m_lo[0]) * r_lo[0], (bf_hi(v[0]) - m_lo[1]) * r_lo[1]);
+        o[1] = pack_bf2((bf_lo(v[1]) - m_lo[2]) * r_lo[2], (bf_hi(v[1]) - m_lo[3]) * r_lo[3]);
+        o[2] = pack_bf2((bf_lo(v[2]) - m_hi[0]) * r_hi[0], (bf_hi(v[2]) - m_hi[1]) * r_hi[1]);
+        o[3] = pack_bf2((bf_lo(v[3]) - m_hi[2]) * r_hi[2], (bf_hi(v[3]) - m_hi[3]) * r_hi[3]);
+        *slot = o;
+      } else if (!a.dres) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(dr) + (pid - XP) * 1024 + lane * 16) = zero4;
+      }
+    }
+    const float rstd_p = st[64 + t / LPP];                              // read before the next tile's statistics are requested
+    __syncthreads();
+    if (active) issue_dy(tile, 1);
+    if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
+    if (active && !(a.dbg & 32)) {
+      wgrad_half(0, xh);
+      stage_dy(1);
+      wave_sync();
+      if (nxt < a.ntiles) issue_dy(nxt, 0);
+      wgrad_half(1, xh);
+    }
+    for_steps(for_steps, std::integral_constant<int, 0>{}, xh);
+    // ---- LayerNorm backward on the finished dxn tile: LPP lanes per pixel, channels sub + LPP j
+    if (!(a.dbg & 8)) {
+      int tt = t;
+      asm volatile("" : "+v"(tt));
+      const int px = tt / LPP, sub = tt % LPP;
+      // swizzled slot of (c = sub + LPP j, px): the chunk term of c splits into a lane part (sub/2) and a constant part (LPP j / 2)
+      constexpr int NVAR = 16 / LPP;                                    // distinct constant parts: LPP 8 -> {0,4}, LPP 4 -> {0,2,4,6}
+      int base[NVAR];
+#pragma unroll
+      for (int v = 0; v < NVAR; ++v) base[v] = sub * 64 + ((((px >> 3) ^ (sub >> 1) ^ ((LPP * v) >> 1)) & 7) << 3) + (px & 7);
+      const short* xs = reinterpret_cast<const short*>(xh);
+      short* ds = reinterpret_cast<short*>(dr);
+      float* const ap = &acc[sub * XS + px];
+      float gv[CPL], xv[CPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        gv[j] = ap[LPP * j * XS];                                       // g = gamma dxn (gamma rides in the W^T fragments)
+        xv[j] = bf_s(xs[base[j % NVAR] + LPP * j * 64]);
+        s1 += gv[j];
+        s2 += gv[j] * xv[j];
+      }
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        short* const slot = ds + base[j % NVAR] + LPP * j * 64;
+        *slot = bf_bits(rstd_p * (gv[j] - m1 - xv[j] * m2) + bf_s(*slot));
+      }
+    }
+    __syncthreads();
+    if (!(a.dbg & 16)) {
+      int tt = t;
+      asm volatile("" : "+v"(tt));
+      const int c0 = tt >> 4, q = tt & 15;                              // rows c0 + (NT/16) i: their swizzle term equals that of c0
+      static_assert((NT / 32) % 8 == 0, "row step of the store loop must keep the swizzle term");
+      const bf16* src = dr + c0 * 64 + ((((q >> 1) ^ (c0 >> 1)) & 7) << 3) + 4 * (q & 1);
+      bf16* const ob = a.dx + (int64_t)b * C * a.N + p0 + (unsigned)c0 * un + 4u * q;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i)
+        *reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un) = *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64);
+    }
+  }
+  // ---- this workgroup's partial G and S
+  if (active) {
+    float* const gp = a.gpart + (int64_t)blockIdx.x * a.M * C;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 16 * i + 4 * g + r;
+          if (m < a.M) gp[(int64_t)m * C + 16 * ct + li] = G[i][ct][r];
+        }
+      float s = S[i];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const int m = m0 + 16 * i + li;
+      if (g == 0 && m < a.mpad) a.spart[(int64_t)blockIdx.x * a.mpad + m] = m < a.M ? s : 0.f;
+    }
+  } else {
+    for (int m = m0 + lane; m < m0 + K::ROWS && m < a.mpad; m += 64) a.spart[(int64_t)blockIdx.x * a.mpad + m] = 0.f;
+  }
+}
+
+// G [M][C], S [M] (already summed over workgroups) -> dW = gamma G + beta S, dgamma = colsum(W o G), dbeta = W^T S.
+// One block per 32 columns, 8 row phases (the matrices are a few hundred KB).
+__global__ __launch_bounds__(256) void bt_finish_kernel(const float* __restrict__ Gs, const float* __restrict__ Ss,
+                                                        const float* __restrict__ w, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ dw,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
+                                                        int accumulate) {
+  __shared__ float sg[8][32], sb[8][32];
+  const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+  float ag = 0.f, ab = 0.f;
+  if (c < C) {
+    const float gc = gamma[c], bc = beta ? beta[c] : 0.f;
+    for (int m = ph; m < M; m += 8) {
+      const float gg = Gs[(int64_t)m * C + c], ss = Ss[m], ww = w[(int64_t)m * C + c];
+      float* o = dw + (int64_t)m * C + c;
+      *o = (accumulate ? *o : 0.f) + gc * gg + bc * ss;
+      ag += ww * gg;
+      ab += ww * ss;
+    }
+  }
+  sg[ph][cx] = ag;
+  sb[ph][cx] = ab;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { tg += sg[k][cx]; tb += sb[k][cx]; }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + tg;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + tb;
+  }
+}
+
+struct BtPlan { int C, NW, MPW, grid, mpad; size_t lds; };
+static bool bt_plan(int M, int C, BtPlan* p) {
+  int nw, mpw;
+  const int mt = (M + 15) / 16;
+  if (C == 96) { nw = 8; mpw = mt <= 24 ? 3 : 4; if (mt > 32) return false; }
+  else if (C == 48) { nw = 4; mpw = mt <= 12 ? 3 : 4; if (mt > 16) return false; }
+  else return false;
+  p->C = C; p->NW = nw; p->MPW = mpw; p->mpad = 16 * nw * mpw;
+  p->lds = C == 96 ? (mpw == 3 ? BtCfg<96, 8, 3>::BYTES : BtCfg<96, 8, 4>::BYTES)
+                   : (mpw == 3 ? BtCfg<48, 4, 3>::BYTES : BtCfg<48, 4, 4>::BYTES);
+  p->grid = C == 96 ? 256 : 512;
+  return true;
+}
+}  // namespace
+
+bool bwd_tail_ok(int M, int C, int64_t N, int dtype) {
+  BtPlan p;
+  return dtype == MI_BF16 && N > 0 && N % 64 == 0 && M >= 16 && bt_plan(M, C, &p);
+}
+// Where the tail beats the three kernels it replaces (tools/bench_tail.py, profiles/r02_d_bwd_tail_bs32.txt): everywhere except
+// the 4-fragments-per-wave form (C = 96, M > 384: 0.92x - it runs at the register limit).  MI_BT_WIDE=1 takes it there too.
+bool bwd_tail_pays(int M, int C) {
+  BtPlan p;
+  if (!bt_plan(M, C, &p)) return false;
+  static const int wide = [] { const char* e = getenv("MI_BT_WIDE"); return e && atoi(e) == 1 ? 1 : 0; }();
+  return !(C == 96 && p.MPW == 4) || wide;
+}
+// partial G / S per workgroup, their sums, and the two-stage row reduction's scratch
+size_t bwd_tail_workspace(int M, int C) {
+  BtPlan p;
+  if (!bt_plan(M, C, &p)) return 0;
+  const size_t mc = (size_t)M * C;
+  return align_up((size_t)p.grid * mc * 4, 256) + align_up((size_t)p.grid * p.mpad * 4, 256) + align_up(mc * 4, 256) +
+         align_up((size_t)p.mpad * 4, 256) + align_up((size_t)REDUCE_GROUPS * (mc > (size_t)p.mpad ? mc : p.mpad) * 4, 256);
+}
+
+template <int C, int NW, int MPW>
+static int bt_launch(const BtArgs& a, int grid, hipStream_t st) {
+  using K = BtCfg<C, NW, MPW>;
+  static bool attr_set = false;   // raising the dynamic-LDS limit is a per-function, per-process setting
+  if (!attr_set) {
+    MI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_kernel<C, NW, MPW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, K::BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bt_kernel<C, NW, MPW>), dim3(grid), dim3(64 * NW), K::BYTES, st, a);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
+                    const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma, float* dbeta,
+                    int B, int64_t N, int accumulate, void* ws, hipStream_t st) {
+  BtPlan p;
+  MI_CHECK_ARG(bt_plan(M, C, &p) && N % 64 == 0, "bwd_tail: unsupported shape M=%d C=%d N=%lld", M, C, (long long)N);
+  MI_CHECK_ARG(dy && x && mean && rstd && w && gamma && dx && dw && dgamma && ws, "bwd_tail: null pointer");
+  MI_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && (!dres || aligned16(dres)) && aligned16(mean) && aligned16(rstd),
+               "bwd_tail: operands must be 16-byte aligned");
+  const size_t mc = (size_t)M * C;
+  Carver cv(ws);
+  float* gpart = cv.take<float>((size_t)p.grid * mc * 4);
+  float* spart = cv.take<float>((size_t)p.grid * p.mpad * 4);
+  float* gsum = cv.take<float>(mc * 4);
+  float* ssum = cv.take<float>((size_t)p.mpad * 4);
+  float* tmp = cv.take<float>((size_t)REDUCE_GROUPS * (mc > (size_t)p.mpad ? mc : p.mpad) * 4);
+  BtArgs a;
+  a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dres = (const bf16*)dres; a.mean = mean; a.rstd = rstd; a.w = w;
+  a.gamma = gamma; a.dx = (bf16*)dx; a.gpart = gpart; a.spart = spart; a.M = M; a.mpad = p.mpad; a.N = N;
+  a.tiles_per_image = (int)(N / 64); a.ntiles = B * a.tiles_per_image;
+  { const char* e = getenv("MI_BT_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  const int grid = a.ntiles < p.grid ? a.ntiles : p.grid;
+  {
+    const double px = (double)B * N;
+    ProfScope ps(st, K_BWD_TAIL, ((double)M + 3.0 * C) * px * 2 + 8.0 * px, 4.0 * M * C * px);
+    if (C == 96 && p.MPW == 4) MI_TRY((bt_launch<96, 8, 4>(a, grid, st)));
+    else if (C == 96) MI_TRY((bt_launch<96, 8, 3>(a, grid, st)));
+    else if (p.MPW == 4) MI_TRY((bt_launch<48, 4, 4>(a, grid, st)));
+    else MI_TRY((bt_launch<48, 4, 3>(a, grid, st)));
+  }
+  MI_TRY(launch_reduce_rows(gpart, gsum, grid, (int64_t)mc, (int64_t)mc, 0, 1.0f, st, tmp));
+  MI_TRY(launch_reduce_rows(spart, ssum, grid, p.mpad, p.mpad, 0, 1.0f, st, tmp));
+  {
+    ProfScope ps(st, K_BWD_TAIL_FIN, 4.0 * mc * 4, 4.0 * mc);
+    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, gsum, ssum, w, gamma, beta, dw, dgamma, dbeta, M,
+                       C, accumulate);
+    MI_LAUNCH_CHECK();
+  }
+  return MI_OK;
+}
+
+}  // namespace mi
+
+// C-ABI: the tail by itself (tests, and callers that build their own half-blocks)
+extern "C" int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype) { return mi::bwd_tail_ok(M, C, N, dtype) ? 1 : 0; }
+extern "C" size_t mi_bwd_tail_workspace(int M, int C) { return mi::bwd_tail_workspace(M, C); }
+extern "C" int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
+                           const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma,
+                           float* dbeta, int B, int64_t N, int accumulate, int dtype, void* ws, void* stream) {
+  MI_CHECK_ARG(dtype == MI_BF16, "bwd_tail: bf16 activations only");
+  return mi::launch_bwd_tail(dy, M, x, C, dres, mean, rstd, w, gamma, beta, dx, dw, dgamma, dbeta, B, N, accumulate, ws,
+                             (hipStream_t)stream);
+}

@@ -42,4 +42,11 @@ int dws_gate_bwd(const DwArgs& a, const void* xin, float* part, int B, bool want
                  hipStream_t st);
 // same, with the conv outputs recomputed from the conv input: a.in = dg, a.gy = conv input x, a.bias = conv bias
 int dws_gate_bwd_recompute(const DwArgs& a, float* part, int B, bool want_dw, int* rows_out, int dtype, hipStream_t st);
+// ---- backward tail of a half-block (bwd_tail.hip): dW, W^T dY, LayerNorm backward and the residual add in one launch ----
+bool bwd_tail_ok(int M, int C, int64_t N, int dtype);
+bool bwd_tail_pays(int M, int C);   // covered AND faster than the unfused chain (the module entry points use the tail only then)
+size_t bwd_tail_workspace(int M, int C);
+int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
+                    const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma, float* dbeta,
+                    int B, int64_t N, int accumulate, void* ws, hipStream_t st);
 }  // namespace mi

@@ -27,6 +27,49 @@ static mi_pw_desc conv1x1(const void* x, int K, const float* w, bool transposed,
   return d;
 }
 
+// ------------------------------------------------------------------ weight gradient beside input gradient
+// The weight-gradient Gram (dW = dY X^T) and the input-gradient GEMM (dX = W^T dY) of one 1x1 conv both stream dY.  Run one
+// after the other over a 32-image batch, the second reads dY from HBM again (2 GB at C = 96: nothing survives in the 256 MiB
+// Infinity Cache).  Launched side by side on two streams they walk dY in the same order, and whichever runs behind finds the
+// other's lines in the Infinity Cache.  MI_CO_STREAM=1 enables it (A/B switch); the side stream and its events are created on
+// first use (i.e. in an eager warm-up step, before any graph capture) and joined back before the entry point returns.
+struct CoStream {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static bool co_stream_enabled() {
+  static const int on = [] { const char* e = getenv("MI_CO_STREAM"); return e && atoi(e) == 1 ? 1 : 0; }();
+  return on != 0;
+}
+static CoStream* co_stream() {
+  static thread_local CoStream cs[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  CoStream& c = cs[dev];
+  if (!c.side) {
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &c;
+}
+// fork: the side stream waits for everything enqueued on `st` so far; returns the stream to launch the side work on
+static hipStream_t co_fork(hipStream_t st) {
+  if (!co_stream_enabled()) return st;
+  CoStream* c = co_stream();
+  if (!c) return st;
+  if (hipEventRecord(c->fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->fork, 0) != hipSuccess) return st;
+  return c->side;
+}
+static int co_join(hipStream_t side, hipStream_t st) {
+  if (side == st) return MI_OK;
+  CoStream* c = co_stream();
+  MI_CHECK_ARG(c != nullptr, "co_join: side stream lost");
+  MI_CHECK_HIP(hipEventRecord(c->join, side));
+  MI_CHECK_HIP(hipStreamWaitEvent(st, c->join, 0));
+  return MI_OK;
+}
+
 // ------------------------------------------------------------------ attention core (shared by MDTA and cross-MDTA)
 // q, k, v are channel slices of NCHW tensors: base pointer + batch stride (elements); heads are contiguous channel
 // groups of c = C/heads rows (Restormer.py:117-119 'b (head c) h w').
@@ -358,8 +401,11 @@ extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
                        stream);
 }
 
-extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* dout, void* dx,
-                           const mi_mdta_grads* gr, const void* saved, void* ws, void* stream) {
+// ln == nullptr: x is the conv input (LayerNorm OUTPUT) and dx its gradient.  ln != nullptr: x is the LayerNorm INPUT; the
+// qkv weight gradient, W_qkv^T dY, the LayerNorm backward and the residual add run as one launch (bwd_tail.hip) and dx is the
+// gradient of the half-block's input.
+static int mdta_bwd_impl(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* dout, void* dx,
+                         const mi_mdta_grads* gr, const void* saved, void* ws, void* stream, const mi_ln_tail* ln) {
   MI_TRY(mdta_check(s));
   MI_CHECK_ARG(p && x && dout && dx && gr && saved && ws, "mdta_bwd: null pointer");
   MI_CHECK_ARG(gr->temperature && gr->qkv_w && gr->dw_w && gr->proj_w, "mdta_bwd: null gradient buffer");
@@ -376,11 +422,38 @@ extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   MI_TRY(mi_dwconv_bwd(w.dqkv, sv.qkv0, p->dw_w, w.dqkv0, gr->dw_w, gr->dw_b, B, 3 * C, s->H, s->W, s->ks, acc, dt, w.dw_ws,
                        stream));
   // qkv 1x1: weight grad (sum over batch), bias grad, input grad
+  if (ln)
+    return launch_bwd_tail(w.dqkv0, 3 * C, x, C, ln->dres, ln->mean, ln->rstd, p->qkv_w, ln->w, ln->b, dx, gr->qkv_w, ln->dw,
+                           ln->db, B, N, acc, (char*)ws + align_up(w.bytes, 256), st);
+  hipStream_t sd = co_fork(st);
   mi_gram_desc g2 = wgrad_gram(w.dqkv0, 3 * C, x, C, B, N, dt, gr->qkv_w, acc);
-  MI_TRY(mi_gram(&g2, w.at.gram_ws, stream));
-  if (gr->qkv_b) MI_TRY(launch_chan_sum(w.dqkv0, gr->qkv_b, B, 3 * C, N, dt, acc, w.at.cs_ws, st));
+  MI_TRY(mi_gram(&g2, w.at.gram_ws, sd));
+  if (gr->qkv_b) MI_TRY(launch_chan_sum(w.dqkv0, gr->qkv_b, B, 3 * C, N, dt, acc, w.at.cs_ws, sd));
   mi_pw_desc dxd = conv1x1(w.dqkv0, 3 * C, p->qkv_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
-  return mi_pw_gemm(&dxd, w.at.pw_ws, stream);
+  MI_TRY(mi_pw_gemm(&dxd, w.at.pw_ws, stream));
+  return co_join(sd, st);
+}
+extern "C" int mi_mdta_bwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* dout, void* dx,
+                           const mi_mdta_grads* gr, const void* saved, void* ws, void* stream) {
+  return mdta_bwd_impl(s, p, x, dout, dx, gr, saved, ws, stream, nullptr);
+}
+static int ln_tail_check(const mi_ln_tail* ln, const char* who) {
+  MI_CHECK_ARG(ln && ln->w && ln->b && ln->mean && ln->rstd && ln->dw && ln->db, "%s: LayerNorm tail needs w, b, mean, rstd, dw, db", who);
+  return MI_OK;
+}
+extern "C" int mi_mdta_bwd_ln_ok(const mi_mdta_shape* s, int qkv_bias) {
+  if (mdta_check(s) != MI_OK || qkv_bias) return 0;
+  return bwd_tail_ok(3 * s->C, s->C, (int64_t)s->H * s->W, s->dtype) && bwd_tail_pays(3 * s->C, s->C) ? 1 : 0;
+}
+extern "C" size_t mi_mdta_bwd_ln_workspace(const mi_mdta_shape* s) {
+  if (!mi_mdta_bwd_ln_ok(s, 0)) return 0;
+  return align_up(mdta_ws_layout(s, nullptr).bytes, 256) + bwd_tail_workspace(3 * s->C, s->C);
+}
+extern "C" int mi_mdta_bwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_tail* ln, const void* x,
+                              const void* dout, void* dx, const mi_mdta_grads* gr, const void* saved, void* ws, void* stream) {
+  MI_TRY(ln_tail_check(ln, "mdta_bwd_ln"));
+  MI_CHECK_ARG(gr && !gr->qkv_b && mi_mdta_bwd_ln_ok(s, 0), "mdta_bwd_ln: shape not covered (bf16, C 48/96, H*W %% 64 == 0, no qkv bias)");
+  return mdta_bwd_impl(s, p, x, dout, dx, gr, saved, ws, stream, ln);
 }
 
 extern "C" size_t mi_xmdta_saved_bytes(const mi_xmdta_shape* s) {
@@ -473,8 +546,8 @@ extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   return MI_OK;
 }
 
-extern "C" int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,
-                           const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream) {
+static int gdfn_bwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,
+                         const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream, const mi_ln_tail* ln) {
   MI_TRY(gdfn_check(s));
   MI_CHECK_ARG(p && x && dout && dx && gr && saved && ws, "gdfn_bwd: null pointer");
   MI_CHECK_ARG(gr->in_w && gr->dw_w && gr->out_w, "gdfn_bwd: null gradient buffer");
@@ -494,10 +567,32 @@ extern "C" int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   else
     MI_TRY(mi_dwconv_gate_bwd(w.dg, sv.h1, sv.h0, p->dw_w, w.dh0, gr->dw_w, gr->dw_b, B, 2 * h, s->H, s->W, s->ks, acc, dt,
                               w.dw_ws, stream));
+  if (ln)
+    return launch_bwd_tail(w.dh0, 2 * h, x, C, ln->dres, ln->mean, ln->rstd, p->in_w, ln->w, ln->b, dx, gr->in_w, ln->dw, ln->db,
+                           B, N, acc, (char*)ws + align_up(w.bytes, 256), st);
+  hipStream_t sd = co_fork(st);
   mi_gram_desc g2 = wgrad_gram(w.dh0, 2 * h, x, C, B, N, dt, gr->in_w, acc);
-  MI_TRY(mi_gram(&g2, w.gram_ws, stream));
-  if (gr->in_b) MI_TRY(launch_chan_sum(w.dh0, gr->in_b, B, 2 * h, N, dt, acc, w.cs_ws, st));
+  MI_TRY(mi_gram(&g2, w.gram_ws, sd));
+  if (gr->in_b) MI_TRY(launch_chan_sum(w.dh0, gr->in_b, B, 2 * h, N, dt, acc, w.cs_ws, sd));
   mi_pw_desc d2 = conv1x1(w.dh0, 2 * h, p->in_w, true, C, nullptr, nullptr, dx, C, B, N, dt);
   MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
-  return MI_OK;
+  return co_join(sd, st);
+}
+extern "C" int mi_gdfn_bwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,
+                           const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream) {
+  return gdfn_bwd_impl(s, p, x, dout, dx, gr, saved, ws, stream, nullptr);
+}
+extern "C" int mi_gdfn_bwd_ln_ok(const mi_gdfn_shape* s, int in_bias) {
+  if (gdfn_check(s) != MI_OK || in_bias) return 0;
+  return bwd_tail_ok(2 * s->hidden, s->C, (int64_t)s->H * s->W, s->dtype) && bwd_tail_pays(2 * s->hidden, s->C) ? 1 : 0;
+}
+extern "C" size_t mi_gdfn_bwd_ln_workspace(const mi_gdfn_shape* s) {
+  if (!mi_gdfn_bwd_ln_ok(s, 0)) return 0;
+  return align_up(gdfn_ws_layout(s, nullptr).bytes, 256) + bwd_tail_workspace(2 * s->hidden, s->C);
+}
+extern "C" int mi_gdfn_bwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_tail* ln, const void* x,
+                              const void* dout, void* dx, const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream) {
+  MI_TRY(ln_tail_check(ln, "gdfn_bwd_ln"));
+  MI_CHECK_ARG(gr && !gr->in_b && mi_gdfn_bwd_ln_ok(s, 0), "gdfn_bwd_ln: shape not covered (bf16, C 48/96, H*W %% 64 == 0, no project_in bias)");
+  return gdfn_bwd_impl(s, p, x, dout, dx, gr, saved, ws, stream, ln);
 }

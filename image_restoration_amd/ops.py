@@ -231,20 +231,49 @@ def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: 
     return out, saved
 
 
+LnTailT = Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor], Tensor, Tensor]   # w, b, mean, rstd, dres, dw, db
+
+
+def _ln_tail(ln: LnTailT, like: Tensor) -> L.LnTail:
+    w, b, mean, rstd, dres, dw, db = ln
+    _gpu(w, b, mean, rstd, dres, dw, db)
+    for t_ in (w, b, mean, rstd, dw, db):
+        _f32(t_, "LayerNorm tail tensor")
+    if dres is not None and (dres.shape != like.shape or dres.dtype != like.dtype):
+        raise ValueError("LayerNorm tail: dres must match the block input")
+    return L.LnTail(_p(w), _p(b), _p(mean), _p(rstd), _p(dres), _p(dw), _p(db))
+
+
+def mdta_bwd_ln_ok(x: Tensor, heads: int, ks: int, qkv_bias: bool) -> bool:
+    """Can the MDTA backward end in the one-launch tail (qkv weight gradient + W^T dY + LayerNorm backward + residual)?"""
+    if not x.is_cuda:
+        return False
+    s = _mdta_shape(x, heads, ks)
+    return bool(L.lib().mi_mdta_bwd_ln_ok(C.byref(s), int(qkv_bias)))
+
+
 def mdta_bwd(x: Tensor, dout: Tensor, params: MdtaParamsT, heads: int, saved: Tensor,
-             grads: Sequence[Optional[Tensor]], accumulate: bool) -> Tensor:
+             grads: Sequence[Optional[Tensor]], accumulate: bool, ln: Optional[LnTailT] = None) -> Tensor:
+    """ln = None: x is the LayerNorm output (the conv input), the result its gradient.  ln given: x is the LayerNorm INPUT
+    and the result the gradient of the half-block's input (mi_mdta_bwd_ln)."""
     _gpu(x, dout, saved, *params, *grads)
     ks = params[3].shape[-1]
     s = _mdta_shape(x, heads, ks)
     lib = L.lib()
     dx = torch.empty_like(x)
-    ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
     pp = _mdta_params(params)
     for t in grads:
         _f32(t, "MDTA gradient")
     gg = L.MdtaGrads(*[_p(t) for t in grads], int(accumulate))
-    L.check(lib.mi_mdta_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
-            "mdta_bwd")
+    if ln is None:
+        ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
+        L.check(lib.mi_mdta_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
+                "mdta_bwd")
+    else:
+        lt = _ln_tail(ln, x)
+        ws = _blob(lib.mi_mdta_bwd_ln_workspace(C.byref(s)), x.device)
+        L.check(lib.mi_mdta_bwd_ln(C.byref(s), C.byref(pp), C.byref(lt), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved),
+                                   _p(ws), _stream()), "mdta_bwd_ln")
     return dx
 
 
@@ -312,8 +341,16 @@ def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_sa
     return out, saved
 
 
+def gdfn_bwd_ln_ok(x: Tensor, hidden: int, ks: int, in_bias: bool) -> bool:
+    if not x.is_cuda:
+        return False
+    s = _gdfn_shape(x, hidden, ks, 0)
+    return bool(L.lib().mi_gdfn_bwd_ln_ok(C.byref(s), int(in_bias)))
+
+
 def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads: Sequence[Optional[Tensor]],
-             accumulate: bool) -> Tensor:
+             accumulate: bool, ln: Optional[LnTailT] = None) -> Tensor:
+    """ln: as in mdta_bwd (x is then the LayerNorm INPUT; mi_gdfn_bwd_ln)."""
     _gpu(x, dout, saved, *params, *grads)
     hidden, ks = params[4].shape[1], params[2].shape[-1]
     lib = L.lib()
@@ -326,13 +363,37 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
     if s is None:
         raise RuntimeError("gdfn_bwd: the saved blob matches neither layout of this shape")
     dx = torch.empty_like(x)
-    ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
     pp = L.GdfnParams(*[_p(t) for t in params])
     for t in grads:
         _f32(t, "GDFN gradient")
     gg = L.GdfnGrads(*[_p(t) for t in grads], int(accumulate))
-    L.check(lib.mi_gdfn_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
-            "gdfn_bwd")
+    if ln is None:
+        ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+        L.check(lib.mi_gdfn_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
+                "gdfn_bwd")
+    else:
+        lt = _ln_tail(ln, x)
+        ws = _blob(lib.mi_gdfn_bwd_ln_workspace(C.byref(s)), x.device)
+        L.check(lib.mi_gdfn_bwd_ln(C.byref(s), C.byref(pp), C.byref(lt), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved),
+                                   _p(ws), _stream()), "gdfn_bwd_ln")
+    return dx
+
+
+def bwd_tail_ok(M: int, Cc: int, N: int, dtype: torch.dtype) -> bool:
+    return bool(L.lib().mi_bwd_tail_ok(M, Cc, N, L.MI_BF16 if dtype == torch.bfloat16 else L.MI_F32))
+
+
+def bwd_tail(dy: Tensor, x: Tensor, dres: Optional[Tensor], mean: Tensor, rstd: Tensor, w: Tensor, gamma: Tensor,
+             beta: Tensor, dw: Tensor, dgamma: Tensor, dbeta: Tensor, accumulate: bool) -> Tensor:
+    """The backward tail by itself (mi_bwd_tail): dy [B,M,H,W], x the LayerNorm input [B,C,H,W]; returns dx."""
+    _gpu(dy, x, dres, mean, rstd, w, gamma, beta, dw, dgamma, dbeta)
+    B, Cc, H, W = x.shape
+    M = dy.shape[1]
+    dx = torch.empty_like(x)
+    lib = L.lib()
+    ws = _blob(lib.mi_bwd_tail_workspace(M, Cc), x.device)
+    L.check(lib.mi_bwd_tail(_p(dy), M, _p(x), Cc, _p(dres), _p(mean), _p(rstd), _p(w), _p(gamma), _p(beta), _p(dx), _p(dw),
+                            _p(dgamma), _p(dbeta), B, H * W, int(accumulate), _dt(x), _p(ws), _stream()), "bwd_tail")
     return dx
 
 

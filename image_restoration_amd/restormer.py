@@ -149,10 +149,16 @@ class _BlockFn(torch.autograd.Function):
         yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
         out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
         if need:
+            # Half-blocks whose backward can end in the one-launch tail (weight gradient + W^T dY + LayerNorm backward +
+            # residual add, csrc/bwd_tail.hip) rebuild LN(x) from x and the statistics: its output is not kept.
+            tail_ok = wb and not os.environ.get("MI_NO_BWD_TAIL")                                    # (A/B switch)
+            ctx.tail_a = tail_ok and ops.mdta_bwd_ln_ok(x, heads, att[3].shape[-1], att[2] is not None)
+            ctx.tail_f = tail_ok and ops.gdfn_bwd_ln_ok(y, ffn[4].shape[1], ffn[2].shape[-1], ffn[1] is not None)
             ctx.heads, ctx.wb = heads, wb
             ctx.mg = _main_grads(params)
             ctx.present = [p is not None for p in params]
-            ctx.save_for_backward(x, xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f, *[p for p in params if p is not None])
+            ctx.save_for_backward(x, None if ctx.tail_a else xn, y, None if ctx.tail_f else yn, mean1, rstd1, mean2, rstd2,
+                                  sv_a, sv_f, *[p for p in params if p is not None])
         return out
 
     @staticmethod
@@ -165,10 +171,16 @@ class _BlockFn(torch.autograd.Function):
         n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
         g1, ga, g2, gf = grads[0:2], grads[2:9], grads[9:11], grads[11:17]
         dout = dout.contiguous()
-        dyn = ops.gdfn_bwd(yn, dout, ffn, sv_f, gf, acc)
-        dy = ops.ln_bwd(dyn, y, n2[0], mean2, rstd2, dout, ctx.wb, g2[0], g2[1], acc)
-        dxn = ops.mdta_bwd(xn, dy, att, ctx.heads, sv_a, ga, acc)
-        dx = ops.ln_bwd(dxn, x, n1[0], mean1, rstd1, dy, ctx.wb, g1[0], g1[1], acc)
+        if ctx.tail_f:
+            dy = ops.gdfn_bwd(y, dout, ffn, sv_f, gf, acc, ln=(n2[0], n2[1], mean2, rstd2, dout, g2[0], g2[1]))
+        else:
+            dyn = ops.gdfn_bwd(yn, dout, ffn, sv_f, gf, acc)
+            dy = ops.ln_bwd(dyn, y, n2[0], mean2, rstd2, dout, ctx.wb, g2[0], g2[1], acc)
+        if ctx.tail_a:
+            dx = ops.mdta_bwd(x, dy, att, ctx.heads, sv_a, ga, acc, ln=(n1[0], n1[1], mean1, rstd1, dy, g1[0], g1[1]))
+        else:
+            dxn = ops.mdta_bwd(xn, dy, att, ctx.heads, sv_a, ga, acc)
+            dx = ops.ln_bwd(dxn, x, n1[0], mean1, rstd1, dy, ctx.wb, g1[0], g1[1], acc)
         return (dx, None) + tuple(None if acc else g for g in grads)
 
 

@@ -244,6 +244,37 @@ int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack, const void
                       float* rstd, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Backward tail of a half-block  out = x + F(LN(x)),  F starting in the 1x1 conv h = W LN(x)
+ * (TransformerBlock.forward, Restormer.py:146-150; qkv :105,115; project_in :82,89; WithBias_LayerNorm :52-64).
+ * One launch computes, from dY = dL/dh:  dW += / = dY LN(x)^T,  dxn = W^T dY,  dx = LNbackward(dxn) + dres,
+ * dgamma, dbeta - dY, x and dres are read once, dx written once; LN(x) is rebuilt from x and the saved statistics.
+ * bf16 activations, C in {48, 96}, M <= 256 (C = 48) / 512 (C = 96), H*W a multiple of 64.
+ *   mi_bwd_tail        : the kernel by itself.  dy [B,M,N], x (LayerNorm INPUT) / dres / dx [B,C,N], mean/rstd [B,N],
+ *                        w [M,C], gamma/beta [C]; dw [M,C], dgamma, dbeta [C] (accumulate: += instead of =).
+ *   mi_mdta_bwd_ln, mi_gdfn_bwd_ln : mi_mdta_bwd / mi_gdfn_bwd with that tail: x is the LayerNorm INPUT, dx the gradient of
+ *                        the half-block's input; workspace from mi_*_bwd_ln_workspace (0 = shape not covered, see *_ok).
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  const float* w; const float* b;        /* LayerNorm weight, bias [C] */
+  const float* mean; const float* rstd;  /* [B, H*W], from mi_ln_fwd */
+  const void* dres;                      /* [B,C,H,W] gradient arriving over the residual connection, or NULL */
+  float* dw; float* db;                  /* LayerNorm parameter gradients [C] */
+} mi_ln_tail;
+int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype);
+size_t mi_bwd_tail_workspace(int M, int C);
+int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
+                const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma, float* dbeta,
+                int B, int64_t N, int accumulate, int dtype, void* ws, void* stream);
+int mi_mdta_bwd_ln_ok(const mi_mdta_shape* s, int qkv_bias);
+size_t mi_mdta_bwd_ln_workspace(const mi_mdta_shape* s);
+int mi_mdta_bwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_tail* ln, const void* x, const void* dout,
+                   void* dx, const mi_mdta_grads* gr, const void* saved, void* ws, void* stream);
+int mi_gdfn_bwd_ln_ok(const mi_gdfn_shape* s, int in_bias);
+size_t mi_gdfn_bwd_ln_workspace(const mi_gdfn_shape* s);
+int mi_gdfn_bwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_tail* ln, const void* x, const void* dout,
+                   void* dx, const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------
  * Training-step tail on flat fp32 buffers (MoCE-IR-main/src/train.py:79-88:
  * AdamW(lr=2e-4), torch defaults betas (0.9,0.999), eps 1e-8, weight_decay 1e-2).
  * p, g, m, v: [n] fp32.  grad_scale multiplies g first (1/world for DDP mean).

@@ -142,3 +142,95 @@ def test_trainer_pack_cache_follows_load_state_dict():
     y_ref = fresh(x).detach().float()
     assert rel(y_loaded, y_ref) < 1e-6, "forward after load_state_dict used stale packed weights"
     assert rel(y_after_steps, y_ref) > 1e-4            # the steps really changed the weights
+
+
+# ------------------------------------------------------------------------------------------------ backward tail (bwd_tail.hip)
+TAIL_CASES = [
+    # C, M, shape of x                  (M = 3C: qkv;  M = 2 * int(2.66 C): project_in)
+    (48, 144, (2, 48, 16, 64)),
+    (48, 254, (3, 48, 8, 72)),        # N = 576 = 9 tiles; 254 rows: the last fragment has 14 valid rows
+    (96, 288, (2, 96, 16, 32)),       # qkv at C = 96: 18 row fragments over 8 waves (two waves idle in the MFMA part)
+    (96, 510, (2, 96, 24, 64)),
+    (96, 510, (5, 96, 64, 64)),       # 320 tiles > 256 workgroups: the persistent loop takes a second tile
+    (48, 96, (1, 48, 8, 8)),          # one tile, few rows
+]
+
+
+def _tail_reference(dy, x, dres, w, gamma, beta):
+    """fp64 statement of what the tail computes (WithBias_LayerNorm, Restormer.py:52-64, eps 1e-5)."""
+    dy, x, dres, w, gamma, beta = (t.detach().cpu().double() for t in (dy, x, dres, w, gamma, beta))
+    B, Cc, H, W = x.shape
+    xf, dyf = x.reshape(B, Cc, -1), dy.reshape(B, dy.shape[1], -1)
+    mu = xf.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xh = (xf - mu) * rstd
+    xn = gamma[None, :, None] * xh + beta[None, :, None]
+    dw = torch.einsum("bmn,bcn->mc", dyf, xn)
+    dxn = torch.einsum("mc,bmn->bcn", w, dyf)
+    g = dxn * gamma[None, :, None]
+    dx = rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True)) + dres.reshape(B, Cc, -1)
+    return dx.reshape(x.shape), dw, (dxn * xh).sum((0, 2)), dxn.sum((0, 2))
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("c,mrows,shape", TAIL_CASES)
+def test_bwd_tail_vs_fp64(c, mrows, shape, accumulate):
+    """dW, W^T dY, LayerNorm backward and the residual add in one launch against fp64 math on the same bf16 inputs.
+    Bounds: bf16 operand rounding of W and of (x - mean) rstd inside the kernel, bf16 storage of dx: 2e-2 of the tensor's
+    largest magnitude for dx, 1e-2 for the three parameter gradients (fp32 accumulation over all pixels)."""
+    from image_restoration_amd import ops
+    B, Cc, H, W = shape
+    assert ops.bwd_tail_ok(mrows, c, H * W, torch.bfloat16)
+    x = (seeded_input(shape, 100 + mrows) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    dy = seeded_input((B, mrows, H, W), 200 + mrows).to(DEV).to(torch.bfloat16)
+    dres = seeded_input(shape, 300 + mrows).to(DEV).to(torch.bfloat16)
+    w = (seeded_input((mrows, c), 400 + mrows) * 0.2).to(DEV).float().contiguous()
+    gamma = (1.0 + 0.3 * seeded_input((c,), 500 + c)).to(DEV).float()
+    beta = (0.2 * seeded_input((c,), 600 + c)).to(DEV).float()
+    _, mean, rstd = ops.ln_fwd(x, gamma, beta, True, want_stats=True)
+    init = 0.5 if accumulate else float("nan")                       # overwrite mode must not read the old contents
+    dw = torch.full((mrows, c), init, device=DEV)
+    dgamma = torch.full((c,), init, device=DEV)
+    dbeta = torch.full((c,), init, device=DEV)
+    dx = ops.bwd_tail(dy, x, dres, mean, rstd, w, gamma, beta, dw, dgamma, dbeta, accumulate)
+    torch.cuda.synchronize()
+    rdx, rdw, rdg, rdb = _tail_reference(dy, x, dres, w, gamma, beta)
+    off = 0.5 if accumulate else 0.0
+    assert rel(dx, rdx) < 2e-2, rel(dx, rdx)
+    assert rel(dw - off, rdw) < 1e-2, rel(dw - off, rdw)
+    assert rel(dgamma - off, rdg) < 1e-2, rel(dgamma - off, rdg)
+    assert rel(dbeta - off, rdb) < 1e-2, rel(dbeta - off, rdb)
+
+
+def test_bwd_tail_rejects_uncovered_shapes():
+    from image_restoration_amd import ops
+    assert not ops.bwd_tail_ok(576, 192, 4096, torch.bfloat16)       # C = 192: unfused chain
+    assert not ops.bwd_tail_ok(288, 96, 4096, torch.float32)         # fp32 stays on the exact chain
+    assert not ops.bwd_tail_ok(288, 96, 4000, torch.bfloat16)        # pixel count not a multiple of the 64-pixel tile
+    assert not ops.bwd_tail_ok(600, 96, 4096, torch.bfloat16)        # more rows than eight waves hold
+
+
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 16, 64)), (96, 2, (2, 96, 16, 32))])
+def test_block_backward_with_and_without_tail(c, heads, shape, monkeypatch):
+    """TransformerBlock forward + backward through the tail kernels (default) and through the unfused chain
+    (MI_NO_BWD_TAIL=1): both within the bf16 bound of the fp64 oracle, for dx and for every parameter gradient."""
+    m = M()
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=31 + c)
+    x0 = seeded_input(shape, 7000 + c)
+    cot = seeded_input(shape, 7001 + c)
+    xr = x0.double().requires_grad_(True)
+    ps = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    R.transformer_block(xr, ps, heads, "WithBias").backward(cot.double())
+    got = {}
+    for mode in ("tail", "chain"):
+        if mode == "chain":
+            monkeypatch.setenv("MI_NO_BWD_TAIL", "1")
+        blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+        blk.load_state_dict(sd)
+        x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        blk(x).backward(cot.to(DEV).to(torch.bfloat16))
+        got[mode] = (x.grad, {k: p.grad for k, p in blk.named_parameters()})
+        assert rel(x.grad, xr.grad) < 3e-2, (mode, rel(x.grad, xr.grad))
+        for k, gk in got[mode][1].items():
+            assert rel(gk, ps[k].grad) < 3e-2, (mode, k, rel(gk, ps[k].grad))
+    assert rel(got["tail"][0], got["chain"][0].float()) < 3e-2
