@@ -433,8 +433,9 @@ bool bwd_tail_ok(int M, int C, int64_t N, int dtype) {
 bool bwd_tail_pays(int M, int C) {
   BtPlan p;
   if (!bt_plan(M, C, &p)) return false;
-  static const int wide = [] { const char* e = getenv("MI_BT_WIDE"); return e && atoi(e) == 1 ? 1 : 0; }();
-  return !(C == 96 && p.MPW == 4) || wide;
+  if (!(C == 96 && p.MPW == 4)) return true;
+  const char* e = getenv("MI_BT_WIDE");                                 // A/B switch, read per call (tests flip it)
+  return e && atoi(e) == 1;
 }
 // partial G / S per workgroup, their sums, and the two-stage row reduction's scratch
 size_t bwd_tail_workspace(int M, int C) {
