@@ -24,7 +24,8 @@ class PwDesc(C.Structure):
                 ("bias", fp), ("bias_gs", c_i64),
                 ("r", vp), ("r_bs", c_i64), ("r_gs", c_i64),
                 ("y", vp), ("y_bs", c_i64), ("y_gs", c_i64),
-                ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int)]
+                ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int),
+                ("ln_w", fp), ("ln_b", fp), ("ln_mean", fp), ("ln_rstd", fp), ("ln_mode", C.c_int)]
 
 
 class GramDesc(C.Structure):
@@ -79,6 +80,10 @@ class GdfnFusedShape(C.Structure):
                 ("ln_with_bias", C.c_int)]
 
 
+class LnHead(C.Structure):
+    _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("with_bias", C.c_int)]
+
+
 class LnTail(C.Structure):
     _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("dres", vp), ("dw", fp), ("db", fp)]
 
@@ -125,6 +130,11 @@ SIGNATURES = {
                                vp, vp]),
     "mi_gdfn_saved_bytes": (C.c_size_t, [C.POINTER(GdfnShape)]),
     "mi_gdfn_workspace": (C.c_size_t, [C.POINTER(GdfnShape)]),
+    "mi_pw_gemm_ln_ok": (C.c_int, [C.POINTER(PwDesc)]),
+    "mi_mdta_fwd_ln_ok": (C.c_int, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fwd_ln": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
+    "mi_gdfn_fwd_ln_ok": (C.c_int, [C.POINTER(GdfnShape)]),
+    "mi_gdfn_fwd_ln": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
     "mi_bwd_tail_ok": (C.c_int, [C.c_int, C.c_int, c_i64, C.c_int]),
     "mi_bwd_tail_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "mi_bwd_tail": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, fp, fp, fp, fp, fp, vp, fp, fp, fp, C.c_int, c_i64, C.c_int,

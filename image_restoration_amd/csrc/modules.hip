@@ -384,8 +384,20 @@ extern "C" size_t mi_mdta_workspace(const mi_mdta_shape* s) {
   return mdta_ws_layout(s, nullptr).bytes;
 }
 
-extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* residual, void* out,
-                           void* saved, void* ws, void* stream) {
+// LayerNorm in front of a 1x1 conv, applied inside the GEMM as the X tile is loaded (mi_pw_desc.ln_*): the normalised tensor
+// never exists in HBM.  ln == nullptr: x is already normalised.
+static void ln_head_apply(mi_pw_desc* d, const mi_ln_head* ln) {
+  if (!ln) return;
+  d->ln_w = ln->w; d->ln_b = ln->with_bias ? ln->b : nullptr; d->ln_mean = ln->mean; d->ln_rstd = ln->rstd;
+  d->ln_mode = ln->with_bias ? 1 : 2;
+}
+static int ln_head_check(const mi_ln_head* ln, const char* who) {
+  MI_CHECK_ARG(ln && ln->w && (!ln->with_bias || ln->b) && ((ln->mean == nullptr) == (ln->rstd == nullptr)),
+               "%s: LayerNorm head needs w (and b for WithBias); mean / rstd both or neither", who);
+  return MI_OK;
+}
+static int mdta_fwd_impl(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* residual, void* out,
+                         void* saved, void* ws, void* stream, const mi_ln_head* ln) {
   MI_TRY(mdta_check(s));
   MI_CHECK_ARG(p && x && out && ws, "mdta_fwd: null pointer");
   MI_CHECK_ARG(p->temperature && p->qkv_w && p->dw_w && p->proj_w, "mdta_fwd: null parameter");
@@ -395,10 +407,27 @@ extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, cons
   MdtaSaved sv = saved ? mdta_saved_layout(s, saved) : w.inf;
   // qkv0 = qkv(x);  qkv = dw(qkv0)                               Restormer.py:114
   mi_pw_desc d1 = conv1x1(x, C, p->qkv_w, false, C, p->qkv_b, nullptr, sv.qkv0, 3 * C, B, N, dt);
+  ln_head_apply(&d1, ln);
   MI_TRY(mi_pw_gemm(&d1, w.at.pw_ws, stream));
   MI_TRY(mi_dwconv_fwd(sv.qkv0, p->dw_w, p->dw_b, sv.qkv, B, 3 * C, s->H, s->W, s->ks, dt, stream));
   return attn_core_fwd(mdta_dims(s), mdta_view(s, sv.qkv), p->temperature, p->proj_w, p->proj_b, residual, out, sv.at, w.at,
                        stream);
+}
+extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* residual, void* out,
+                           void* saved, void* ws, void* stream) {
+  return mdta_fwd_impl(s, p, x, residual, out, saved, ws, stream, nullptr);
+}
+extern "C" int mi_mdta_fwd_ln_ok(const mi_mdta_shape* s) {
+  if (mdta_check(s) != MI_OK) return 0;
+  mi_pw_desc d = conv1x1((void*)256, s->C, (const float*)256, false, s->C, nullptr, nullptr, (void*)256, 3 * s->C, s->B,
+                         (int64_t)s->H * s->W, s->dtype);
+  return mi_pw_gemm_ln_ok(&d);
+}
+extern "C" int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const void* x,
+                              const void* residual, void* out, void* saved, void* ws, void* stream) {
+  MI_TRY(ln_head_check(ln, "mdta_fwd_ln"));
+  MI_CHECK_ARG(mi_mdta_fwd_ln_ok(s), "mdta_fwd_ln: shape not covered (bf16, C <= 96, H*W %% 64 == 0)");
+  return mdta_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
 }
 
 // ln == nullptr: x is the conv input (LayerNorm OUTPUT) and dx its gradient.  ln != nullptr: x is the LayerNorm INPUT; the
@@ -528,8 +557,8 @@ extern "C" size_t mi_gdfn_workspace(const mi_gdfn_shape* s) {
   return gdfn_ws_layout(s, nullptr).bytes;
 }
 
-extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* residual, void* out,
-                           void* saved, void* ws, void* stream) {
+static int gdfn_fwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* residual, void* out,
+                         void* saved, void* ws, void* stream, const mi_ln_head* ln) {
   MI_TRY(gdfn_check(s));
   MI_CHECK_ARG(p && x && out && ws, "gdfn_fwd: null pointer");
   MI_CHECK_ARG(p->in_w && p->dw_w && p->out_w, "gdfn_fwd: null parameter");
@@ -538,12 +567,29 @@ extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, cons
   GdfnWs w = gdfn_ws_layout(s, ws);
   GdfnSaved sv = saved ? gdfn_saved_layout(s, saved) : w.inf;
   mi_pw_desc d1 = conv1x1(x, C, p->in_w, false, C, p->in_b, nullptr, sv.h0, 2 * h, B, N, dt);       // Restormer.py:89
+  ln_head_apply(&d1, ln);
   MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
   MI_TRY(mi_dwconv_gate_fwd(sv.h0, p->dw_w, p->dw_b, (saved && !gdfn_recompute(s)) ? sv.h1 : nullptr, sv.g, B, 2 * h, s->H,
                             s->W, s->ks, dt, stream));                                               // :90-91
   mi_pw_desc d2 = conv1x1(sv.g, h, p->out_w, false, h, p->out_b, residual, out, C, B, N, dt);       // :92
   MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
+}
+extern "C" int mi_gdfn_fwd(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* residual, void* out,
+                           void* saved, void* ws, void* stream) {
+  return gdfn_fwd_impl(s, p, x, residual, out, saved, ws, stream, nullptr);
+}
+extern "C" int mi_gdfn_fwd_ln_ok(const mi_gdfn_shape* s) {
+  if (gdfn_check(s) != MI_OK) return 0;
+  mi_pw_desc d = conv1x1((void*)256, s->C, (const float*)256, false, s->C, nullptr, nullptr, (void*)256, 2 * s->hidden, s->B,
+                         (int64_t)s->H * s->W, s->dtype);
+  return mi_pw_gemm_ln_ok(&d);
+}
+extern "C" int mi_gdfn_fwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const void* x,
+                              const void* residual, void* out, void* saved, void* ws, void* stream) {
+  MI_TRY(ln_head_check(ln, "gdfn_fwd_ln"));
+  MI_CHECK_ARG(mi_gdfn_fwd_ln_ok(s), "gdfn_fwd_ln: shape not covered (bf16, C <= 96, H*W %% 64 == 0)");
+  return gdfn_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
 }
 
 static int gdfn_bwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,

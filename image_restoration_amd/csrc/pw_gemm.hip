@@ -106,6 +106,8 @@ struct PwG {
   const unsigned char* ws;  // [zero block][packed weights]
   int64_t wp_slice;         // elements per packed slice
   int wp_per_batch, wp_per_group, k_chunks;
+  // LayerNorm of X applied on the way in (xres form only): gamma / beta [K], statistics out [batch][n] (or null)
+  const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;   // 0 none, 1 WithBias, 2 BiasFree
 };
 
 // X chunk addressing in LDS.  Register-staged image: [32][PW_XS] padded rows.  LDS-DMA image: [32][64] unpadded rows
@@ -679,6 +681,83 @@ __device__ __forceinline__ void pww_store_bf16(const f32x4 (&acc0)[4], const f32
   wave_lds_sync();
 }
 
+// LayerNorm over the channels of one 64-pixel X tile while it sits in the raw load registers (instruction i of chunk kb holds
+// row kb*32 + 8i + lane/8, pixels 8 (lane & 7) .. +7): per-pixel sums run over the lane's rows, then over the 8 lanes that share
+// (lane & 7).  Same arithmetic as ln.hip (two-pass variance, (v - mu) * rstd * gamma + beta).  lnp: gamma[32 KB] | beta[32 KB] in LDS.
+template <int KB>
+__device__ __forceinline__ void pww_ln_inplace(u32x4 (&raw)[KB][4], int ktot, const float* lnp, int mode, float* mean_out,
+                                               float* rstd_out, int lane) {
+  const int r0 = lane >> 3;
+  float s[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (kb * PW_KC + 8 * i + r0 < ktot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[2 * j] += bf16_bits_to_f32(raw[kb][i][j] & 0xffffu);
+          s[2 * j + 1] += bf16_bits_to_f32(raw[kb][i][j] >> 16);
+        }
+      }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] += __shfl_xor(s[j], 8);
+    s[j] += __shfl_xor(s[j], 16);
+    s[j] += __shfl_xor(s[j], 32);
+  }
+  const float inv = 1.0f / (float)ktot;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mu[j] = s[j] * inv; s[j] = 0.f; }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (kb * PW_KC + 8 * i + r0 < ktot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d0 = bf16_bits_to_f32(raw[kb][i][j] & 0xffffu) - mu[2 * j];
+          const float d1 = bf16_bits_to_f32(raw[kb][i][j] >> 16) - mu[2 * j + 1];
+          s[2 * j] += d0 * d0;
+          s[2 * j + 1] += d1 * d1;
+        }
+      }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] += __shfl_xor(s[j], 8);
+    s[j] += __shfl_xor(s[j], 16);
+    s[j] += __shfl_xor(s[j], 32);
+    rs[j] = 1.0f / sqrtf(s[j] * inv + 1e-5f);
+  }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kb * PW_KC + 8 * i + r0;
+      if (k < ktot) {
+        const float g = lnp[k], b = lnp[KB * PW_KC + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = bf16_bits_to_f32(raw[kb][i][j] & 0xffffu), v1 = bf16_bits_to_f32(raw[kb][i][j] >> 16);
+          const float o0 = mode == 1 ? (v0 - mu[2 * j]) * rs[2 * j] * g + b : v0 * rs[2 * j] * g;
+          const float o1 = mode == 1 ? (v1 - mu[2 * j + 1]) * rs[2 * j + 1] * g + b : v1 * rs[2 * j + 1] * g;
+          const bf16 h0 = (bf16)o0, h1 = (bf16)o1;
+          raw[kb][i][j] = (unsigned)__builtin_bit_cast(u16, h0) | ((unsigned)__builtin_bit_cast(u16, h1) << 16);
+        }
+      }
+    }
+  if (mean_out && r0 == 0) {
+    float* mo = mean_out + 8 * (lane & 7);
+    float* ro = rstd_out + 8 * (lane & 7);
+    *reinterpret_cast<f32x4*>(mo) = (f32x4){mu[0], mu[1], mu[2], mu[3]};
+    *reinterpret_cast<f32x4*>(mo + 4) = (f32x4){mu[4], mu[5], mu[6], mu[7]};
+    *reinterpret_cast<f32x4*>(ro) = (f32x4){rs[0], rs[1], rs[2], rs[3]};
+    *reinterpret_cast<f32x4*>(ro + 4) = (f32x4){rs[4], rs[5], rs[6], rs[7]};
+  }
+}
+
 template <int KB>
 __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, int m_tiles, int tiles_per_wave, int chunk_stride_elems) {
   const PwK& p = q.k;
@@ -691,6 +770,13 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
   pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, m_tiles * KB, TM,
                     chunk_stride_elems, t);
+  float* const lnp = reinterpret_cast<float*>(Wl + (int64_t)m_tiles * KB * TM * WS_ROW + PWW_MW * PWW_PATCH);   // gamma | beta
+  if (q.ln_mode) {
+    for (int i = t; i < KB * PW_KC; i += 64 * PWW_MW) {
+      lnp[i] = i < p.k1 ? q.ln_w[i] : 0.f;
+      lnp[KB * PW_KC + i] = (i < p.k1 && q.ln_b) ? q.ln_b[i] : 0.f;
+    }
+  }
   __syncthreads();                                                   // the only workgroup barrier
   PwwX x;
   x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
@@ -712,6 +798,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
     const int64_t tile = tile0 + tt;
     if (tile >= n_tiles) break;
     const int64_t n0 = tile * PW_TN;
+    if (q.ln_mode)
+      pww_ln_inplace<KB>(raw, x.ktot, lnp, q.ln_mode, q.ln_mean ? q.ln_mean + zb * p.n + n0 : nullptr,
+                         q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, lane);
     s16x8 a[KB][4];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) pww_chunk_to_frags(a[kb], raw[kb], patch, kb, x.ktot, lane);
@@ -874,7 +963,7 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
     const bool off = (e && e[0] == '0') || getenv("MI_PW_DMA") || getenv("MI_PW_CHUNKED");
     if (allow_wave && !off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
       const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
-      if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches <= PWW_LDS_MAX) {
+      if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches + 768 <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
       } else {
         // stream: one 96- / 64- / 48-channel tile per workgroup; wide outputs tile M (every tile streams X again, like the
@@ -979,6 +1068,13 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   PwG q;
   q.k = k; q.ws = cached ? cached : (const unsigned char*)ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch;
   q.wp_per_group = pl.per_group; q.k_chunks = pl.k_chunks;
+  q.ln_w = d->ln_w; q.ln_b = d->ln_b; q.ln_mean = d->ln_mean; q.ln_rstd = d->ln_rstd; q.ln_mode = d->ln_mode;
+  if (d->ln_mode) {
+    MI_CHECK_ARG(pl.wave == 1 && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
+                     (d->ln_mode == 1 || d->ln_mode == 2) && (d->ln_mean == nullptr) == (d->ln_rstd == nullptr),
+                 "pw_gemm: LayerNorm-on-load needs the X-resident form (bf16, 96 < M, K <= 96, one K panel, one group; "
+                 "mi_pw_gemm_ln_ok)");
+  }
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
   if (grid.y > 65535 || grid.z > 65535) { set_error("pw_gemm: grid too large"); return MI_ERR_ARG; }
   const double Z = (double)d->batch * k.groups, kt = k.k1 + k.k2;
@@ -1004,7 +1100,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
       if (tpw < 1) tpw = 1;
       if (tpw > 8) tpw = 8;
       dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), pl.wave == 2 ? pl.m_tiles : 1, grid.z), wblock(64 * PWW_MW);
-      const size_t lds = wbytes + patches;
+      const size_t lds = wbytes + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
 #define PWW_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                       \
     if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1097,6 +1193,11 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == MI_F32) return pw_launch<float>(d, k, pl, ws, st);
   return pw_launch<bf16>(d, k, pl, ws, st);
+}
+
+extern "C" int mi_pw_gemm_ln_ok(const mi_pw_desc* d) {
+  if (!d || pw_check(d) != MI_OK || d->k2 != 0 || d->groups != 1) return 0;
+  return pw_plan(d).wave == 1 ? 1 : 0;
 }
 
 extern "C" int mi_pw_cache_enable(void* buf, size_t bytes, const void* params_lo, const void* params_hi) {

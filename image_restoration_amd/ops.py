@@ -216,8 +216,33 @@ def _mdta_params(p: Sequence[Optional[Tensor]]) -> L.MdtaParams:
     return L.MdtaParams(*[_p(t) for t in p])
 
 
-def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: int, need_saved: bool):
-    """params = (temperature, qkv.weight, qkv.bias, qkv_dwconv.weight, qkv_dwconv.bias, project_out.weight, .bias)."""
+LnHeadT = Tuple[Tensor, Optional[Tensor], bool]     # LayerNorm weight, bias, want_stats
+
+
+def _ln_head(ln: LnHeadT, x: Tensor):
+    w, b, want_stats = ln
+    _gpu(w, b)
+    _f32(w, "LayerNorm weight"); _f32(b, "LayerNorm bias")
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((x.shape[0], x.shape[2] * x.shape[3]), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    return L.LnHead(_p(w), _p(b), _p(mean), _p(rstd), int(b is not None)), mean, rstd
+
+
+def mdta_fwd_ln_ok(x: Tensor, heads: int, ks: int) -> bool:
+    """Can norm1 run inside the qkv GEMM (mi_mdta_fwd_ln)?"""
+    if not x.is_cuda:
+        return False
+    s = _mdta_shape(x, heads, ks)
+    return bool(L.lib().mi_mdta_fwd_ln_ok(C.byref(s)))
+
+
+def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: int, need_saved: bool,
+             ln: Optional[LnHeadT] = None):
+    """params = (temperature, qkv.weight, qkv.bias, qkv_dwconv.weight, qkv_dwconv.bias, project_out.weight, .bias).
+    ln = (weight, bias, want_stats): x is the LayerNorm INPUT and the norm runs inside the qkv GEMM; returns
+    (out, saved, mean, rstd) then."""
     _gpu(x, residual, *params)
     ks = params[3].shape[-1]
     s = _mdta_shape(x, heads, ks)
@@ -226,9 +251,14 @@ def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: 
     saved = _blob(lib.mi_mdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
     ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
     pp = _mdta_params(params)
-    L.check(lib.mi_mdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
-            "mdta_fwd")
-    return out, saved
+    if ln is None:
+        L.check(lib.mi_mdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
+                "mdta_fwd")
+        return out, saved
+    lh, mean, rstd = _ln_head(ln, x)
+    L.check(lib.mi_mdta_fwd_ln(C.byref(s), C.byref(pp), C.byref(lh), _p(x), _p(residual), _p(out), _p(saved), _p(ws),
+                               _stream()), "mdta_fwd_ln")
+    return out, saved, mean, rstd
 
 
 LnTailT = Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor], Tensor, Tensor]   # w, b, mean, rstd, dres, dw, db
@@ -322,8 +352,15 @@ def _gdfn_shape(x: Tensor, hidden: int, ks: int, flags: int = 0) -> L.GdfnShape:
     return L.GdfnShape(B, Cc, hidden, H, W, _dt(x), ks, flags)
 
 
-def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool):
-    """params = (project_in.weight, .bias, dwconv.weight, .bias, project_out.weight, .bias)."""
+def gdfn_fwd_ln_ok(x: Tensor, hidden: int, ks: int) -> bool:
+    if not x.is_cuda:
+        return False
+    s = _gdfn_shape(x, hidden, ks, 0)
+    return bool(L.lib().mi_gdfn_fwd_ln_ok(C.byref(s)))
+
+
+def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool, ln: Optional[LnHeadT] = None):
+    """params = (project_in.weight, .bias, dwconv.weight, .bias, project_out.weight, .bias).  ln: as in mdta_fwd."""
     _gpu(x, residual, *params)
     for t in params:
         _f32(t, "GDFN parameter")
@@ -336,9 +373,14 @@ def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_sa
     saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(s)), x.device) if need_saved else None
     ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
     pp = L.GdfnParams(*[_p(t) for t in params])
-    L.check(lib.mi_gdfn_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
-            "gdfn_fwd")
-    return out, saved
+    if ln is None:
+        L.check(lib.mi_gdfn_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
+                "gdfn_fwd")
+        return out, saved
+    lh, mean, rstd = _ln_head(ln, x)
+    L.check(lib.mi_gdfn_fwd_ln(C.byref(s), C.byref(pp), C.byref(lh), _p(x), _p(residual), _p(out), _p(saved), _p(ws),
+                               _stream()), "gdfn_fwd_ln")
+    return out, saved, mean, rstd
 
 
 def gdfn_bwd_ln_ok(x: Tensor, hidden: int, ks: int, in_bias: bool) -> bool:

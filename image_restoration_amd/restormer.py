@@ -144,20 +144,31 @@ class _BlockFn(torch.autograd.Function):
         ffn = params[11:17]
         need = _grad_mode() and any(ctx.needs_input_grad)
         wb = n1[1] is not None
-        xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
-        y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
-        yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
-        out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
+        # Half-blocks whose backward can end in the one-launch tail (weight gradient + W^T dY + LayerNorm backward +
+        # residual add, csrc/bwd_tail.hip) rebuild LN(x) from x and the statistics, so its output is not kept - and where the
+        # first 1x1 conv can normalise its input as it loads it (mi_*_fwd_ln) it is never written at all.
+        ks_a, hidden, ks_f = att[3].shape[-1], ffn[4].shape[1], ffn[2].shape[-1]
+        tail_ok = need and wb and not os.environ.get("MI_NO_BWD_TAIL")                                # (A/B switches)
+        tail_a = tail_ok and ops.mdta_bwd_ln_ok(x, heads, ks_a, att[2] is not None)
+        tail_f = tail_ok and ops.gdfn_bwd_ln_ok(x, hidden, ks_f, ffn[1] is not None)
+        head_ok = not os.environ.get("MI_NO_LN_HEAD")
+        xn = yn = None
+        if head_ok and (tail_a or not need) and ops.mdta_fwd_ln_ok(x, heads, ks_a):
+            y, sv_a, mean1, rstd1 = ops.mdta_fwd(x, x, att, heads, need, ln=(n1[0], n1[1], need))
+        else:
+            xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
+            y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
+        if head_ok and (tail_f or not need) and ops.gdfn_fwd_ln_ok(y, hidden, ks_f):
+            out, sv_f, mean2, rstd2 = ops.gdfn_fwd(y, y, ffn, need, ln=(n2[0], n2[1], need))
+        else:
+            yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
+            out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
         if need:
-            # Half-blocks whose backward can end in the one-launch tail (weight gradient + W^T dY + LayerNorm backward +
-            # residual add, csrc/bwd_tail.hip) rebuild LN(x) from x and the statistics: its output is not kept.
-            tail_ok = wb and not os.environ.get("MI_NO_BWD_TAIL")                                    # (A/B switch)
-            ctx.tail_a = tail_ok and ops.mdta_bwd_ln_ok(x, heads, att[3].shape[-1], att[2] is not None)
-            ctx.tail_f = tail_ok and ops.gdfn_bwd_ln_ok(y, ffn[4].shape[1], ffn[2].shape[-1], ffn[1] is not None)
+            ctx.tail_a, ctx.tail_f = tail_a, tail_f
             ctx.heads, ctx.wb = heads, wb
             ctx.mg = _main_grads(params)
             ctx.present = [p is not None for p in params]
-            ctx.save_for_backward(x, None if ctx.tail_a else xn, y, None if ctx.tail_f else yn, mean1, rstd1, mean2, rstd2,
+            ctx.save_for_backward(x, None if tail_a else xn, y, None if tail_f else yn, mean1, rstd1, mean2, rstd2,
                                   sv_a, sv_f, *[p for p in params if p is not None])
         return out
 
@@ -203,8 +214,12 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
     _gpu_block_input(x)
     n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
     wb = n1[1] is not None
-    xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
-    y, _ = ops.mdta_fwd(xn, x, att, block.attn.num_heads, False)
+    heads = block.attn.num_heads
+    if ops.mdta_fwd_ln_ok(x, heads, att[3].shape[-1]) and not os.environ.get("MI_NO_LN_HEAD"):   # norm1 inside the qkv GEMM
+        y = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], False))[0]
+    else:
+        xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
+        y, _ = ops.mdta_fwd(xn, x, att, heads, False)
     hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
     if ops.gdfn_fused_ok(y, hidden, ks) and not os.environ.get("MI_NO_FUSED_INFER"):      # (A/B switch)
         pack = _fused_gdfn_pack(block, y, n2, ffn)

@@ -109,9 +109,15 @@ typedef struct {
   const void* r; int64_t r_bs, r_gs;              /* residual, may be NULL */
   void* y; int64_t y_bs, y_gs;
   int m; int64_t n; int batch; int groups; int dtype;
+  /* Optional LayerNorm over the K channels of X1, applied as the tile is loaded (Restormer.py:27-70 in front of :89 / :115):
+   * ln_mode 0 = none, 1 = WithBias ((x - mu) rstd w + b), 2 = BiasFree (x rstd w); ln_w / ln_b [K]; ln_mean / ln_rstd
+   * [batch, n] receive the statistics (both or neither).  Only where mi_pw_gemm_ln_ok() says so (the X-resident kernel:
+   * bf16, 96 < M, K <= 96, one K panel, one group); zero-initialise the struct to leave it off. */
+  const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;
 } mi_pw_desc;
 size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
 int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
+int mi_pw_gemm_ln_ok(const mi_pw_desc* d);
 
 /* Opt-in packed-weight cache.  By default every mi_pw_gemm (and every module entry point built on it) packs its weight
  * matrix into its own workspace, once per call, and the library keeps no state.  A caller that controls when the
@@ -260,6 +266,16 @@ typedef struct {
   const void* dres;                      /* [B,C,H,W] gradient arriving over the residual connection, or NULL */
   float* dw; float* db;                  /* LayerNorm parameter gradients [C] */
 } mi_ln_tail;
+/* LayerNorm in front of the half-block's first 1x1 conv, applied inside that GEMM (the normalised tensor never reaches HBM):
+ * mi_mdta_fwd_ln / mi_gdfn_fwd_ln = mi_mdta_fwd / mi_gdfn_fwd with x the LayerNorm INPUT.  mean / rstd [B, H*W] receive the
+ * statistics for the backward pass (both or neither).  Shapes: mi_*_fwd_ln_ok (bf16, C <= 96, H*W a multiple of 64). */
+typedef struct { const float* w; const float* b; float* mean; float* rstd; int with_bias; } mi_ln_head;
+int mi_mdta_fwd_ln_ok(const mi_mdta_shape* s);
+int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const void* x, const void* residual,
+                   void* out, void* saved, void* ws, void* stream);
+int mi_gdfn_fwd_ln_ok(const mi_gdfn_shape* s);
+int mi_gdfn_fwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const void* x, const void* residual,
+                   void* out, void* saved, void* ws, void* stream);
 int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype);
 size_t mi_bwd_tail_workspace(int M, int C);
 int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,

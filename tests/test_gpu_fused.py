@@ -236,3 +236,40 @@ def test_block_backward_with_and_without_tail(c, heads, shape, monkeypatch):
         for k, gk in got[mode][1].items():
             assert rel(gk, ps[k].grad) < 3e-2, (mode, k, rel(gk, ps[k].grad))
     assert rel(got["tail"][0], got["chain"][0].float()) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm inside the first 1x1 conv
+@pytest.mark.parametrize("kind", ["WithBias", "BiasFree"])
+@pytest.mark.parametrize("c,heads,f,shape", [(48, 1, 2.66, (2, 48, 16, 64)), (96, 2, 2.66, (2, 96, 8, 64)), (64, 2, 2.0, (1, 64, 16, 32))])
+def test_ln_head_inside_first_gemm(c, heads, f, shape, kind):
+    """mi_mdta_fwd_ln / mi_gdfn_fwd_ln (LayerNorm applied as the GEMM loads its tile) against ln_fwd followed by the plain entry
+    points: same arithmetic, so the two agree to a few bf16 ulps (5e-3 of the largest magnitude; the summation order of the
+    statistics differs), and the statistics agree to 1e-5."""
+    from image_restoration_amd import ops
+    sd = R.make_block_state(c, heads, f, False, kind, seed=51 + c)
+    dev = lambda k: sd[k].to(DEV).float().contiguous() if k in sd else None
+    att = (dev("attn.temperature"), dev("attn.qkv.weight"), dev("attn.qkv.bias"), dev("attn.qkv_dwconv.weight"),
+           dev("attn.qkv_dwconv.bias"), dev("attn.project_out.weight"), dev("attn.project_out.bias"))
+    ffn = _ffn_params(sd, DEV)
+    x = (seeded_input(shape, 8100 + c) * 1.7 + 0.4).to(DEV).to(torch.bfloat16)
+    wb = kind == "WithBias"
+    n1 = (dev("norm1.body.weight"), dev("norm1.body.bias"))
+    n2 = (dev("norm2.body.weight"), dev("norm2.body.bias"))
+    assert ops.mdta_fwd_ln_ok(x, heads, 3) and ops.gdfn_fwd_ln_ok(x, ffn[4].shape[1], 3)
+    xn, mean, rstd = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=True)
+    ref, _ = ops.mdta_fwd(xn, x, att, heads, False)
+    got, _, m2, r2 = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], True))
+    assert rel(got, ref.float()) < 5e-3, rel(got, ref.float())
+    assert rel(m2, mean) < 1e-5 and rel(r2, rstd) < 1e-5
+    yn, mean, rstd = ops.ln_fwd(x, n2[0], n2[1], wb, want_stats=True)
+    ref, _ = ops.gdfn_fwd(yn, x, ffn, False)
+    got, _, m2, r2 = ops.gdfn_fwd(x, x, ffn, False, ln=(n2[0], n2[1], True))
+    assert rel(got, ref.float()) < 5e-3, rel(got, ref.float())
+    assert rel(m2, mean) < 1e-5 and rel(r2, rstd) < 1e-5
+
+
+def test_ln_head_rejects_uncovered_shapes():
+    from image_restoration_amd import ops
+    assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 192, 16, 64), dtype=torch.bfloat16, device=DEV), 4, 3)   # K > 96
+    assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 16, 64), dtype=torch.float32, device=DEV), 1, 3)     # fp32
+    assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 10, 10), dtype=torch.bfloat16, device=DEV), 1, 3)    # ragged plane
