@@ -209,8 +209,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   // 64 x C output tile is cut into NW slices of three 16 x 16 fragments; in step s wave w owns slice (w + s) mod NW: it loads
   // the running sum as the MFMA accumulator input (step 0: zero), adds its rows' contribution and stores it back.  A barrier
   // separates steps.
-  auto dxn_step = [&](auto sc, const bf16* xh) {
-    constexpr int s = decltype(sc)::value;
+  auto dxn_step = [&](int s) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int li_ = ln & 15, g_ = ln >> 4, qq_ = li_ >> 2, pp_ = li_ & 3;
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];   // 4 consecutive pixels of one channel
     f32x4 d[3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) d[u] = s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ap0 + 16 * u * XS);
+    for (int u = 0; u < 3; ++u) d[u] = s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ap0 + 16 * u * XS);   // (s is uniform)
     if (skip) return;
     if (KS == 1) lds_wait(lo[0], hi[0]);
     else lds_wait(lo[0], hi[0], lo[KS - 1], hi[KS - 1]);
@@ -251,15 +250,6 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];
 #pragma unroll
     for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  };
-  auto for_steps = [&](auto self, auto sc, const bf16* xh) -> void {
-    constexpr int s = decltype(sc)::value;
-    if constexpr (s < NW) {
-      if (active && !(a.dbg & 32)) dxn_step(sc, xh);
-      else if (s == 0) dxn_zero();
-      __syncthreads();
-      self(self, std::integral_constant<int, s + 1>{}, xh);
-    }
   };
 
   int tile = blockIdx.x;
@@ -307,7 +297,20 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       if (nxt < a.ntiles) issue_dy(nxt, 0);
       wgrad_half(1, xh);
     }
-    for_steps(for_steps, std::integral_constant<int, 0>{}, xh);
+    // (rolled for the 4-fragment form: unrolled, its eight copies push that kernel from 4 to 13 spilled registers)
+    auto step = [&](int sstep) {
+      if (active && !(a.dbg & 32)) dxn_step(sstep);
+      else if (sstep == 0) dxn_zero();
+      __syncthreads();
+    };
+    if constexpr (MPW == 4) {   // (rolled: unrolled, the eight copies push this form from 0 to 13 spilled registers; the
+                                // 3-fragment forms are 4 % faster unrolled)
+#pragma unroll 1
+      for (int sstep = 0; sstep < NW; ++sstep) step(sstep);
+    } else {
+#pragma unroll
+      for (int sstep = 0; sstep < NW; ++sstep) step(sstep);
+    }
     // ---- LayerNorm backward on the finished dxn tile: LPP lanes per pixel, channels sub + LPP j
     if (!(a.dbg & 8)) {
       int tt = t;
@@ -428,14 +431,14 @@ bool bwd_tail_ok(int M, int C, int64_t N, int dtype) {
   BtPlan p;
   return dtype == MI_BF16 && N > 0 && N % 64 == 0 && M >= 16 && bt_plan(M, C, &p);
 }
-// Where the tail beats the three kernels it replaces (tools/bench_tail.py, profiles/r02_d_bwd_tail_bs32.txt): everywhere except
-// the 4-fragments-per-wave form (C = 96, M > 384: 0.92x - it runs at the register limit).  MI_BT_WIDE=1 takes it there too.
+// Where the tail beats the three kernels it replaces (tools/bench_tail.py, profiles/r02_d_bwd_tail_bs32.txt): every covered
+// shape, 1.06-1.30x.  (The 4-fragments-per-wave form, C = 96 and M > 384, runs at the register limit: with its reduction steps
+// unrolled it spilled 13 registers and lost, 0.92x; rolled it wins 1.10x.  MI_BT_WIDE=0 switches it off.)
 bool bwd_tail_pays(int M, int C) {
   BtPlan p;
   if (!bt_plan(M, C, &p)) return false;
-  if (!(C == 96 && p.MPW == 4)) return true;
-  const char* e = getenv("MI_BT_WIDE");                                 // A/B switch, read per call (tests flip it)
-  return e && atoi(e) == 1;
+  const char* e = getenv("MI_BT_WIDE");                                 // A/B switch, read per call: 0 keeps the 4-fragment form off
+  return !(C == 96 && p.MPW == 4) || !(e && atoi(e) == 0);
 }
 // partial G / S per workgroup, their sums, and the two-stage row reduction's scratch
 size_t bwd_tail_workspace(int M, int C) {

@@ -213,10 +213,9 @@ def test_bwd_tail_rejects_uncovered_shapes():
 @pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 16, 64)), (96, 2, (2, 96, 16, 32))])
 def test_block_backward_with_and_without_tail(c, heads, shape, monkeypatch):
     """TransformerBlock forward + backward through the tail kernels and through the unfused chain (MI_NO_BWD_TAIL=1): both
-    within the bf16 bound of the fp64 oracle, for dx and for every parameter gradient.  MI_BT_WIDE=1 so that the GDFN half
-    of the C = 96 block (510 rows, off by default: slower than the chain) goes through the tail as well."""
+    within the bf16 bound of the fp64 oracle, for dx and for every parameter gradient (at C = 96 the GDFN half takes the
+    4-fragment form of the kernel, 510 rows)."""
     m = M()
-    monkeypatch.setenv("MI_BT_WIDE", "1")
     sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=31 + c)
     x0 = seeded_input(shape, 7000 + c)
     cot = seeded_input(shape, 7001 + c)
