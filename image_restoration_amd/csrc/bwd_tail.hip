@@ -44,8 +44,7 @@ struct BtArgs {
   const float* w;      // [M][C]
   const float* gamma;  // [C]
   bf16* dx;            // [B][C][N]
-  float* gpart;        // [grid][M][C]
-  float* spart;        // [grid][mpad]
+  float* gpart;        // [grid][M][C + 1]: G and, in column C, the row sums S
   int M, mpad;
   int64_t N;
   int tiles_per_image;
@@ -357,9 +356,9 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
         *reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un) = *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64);
     }
   }
-  // ---- this workgroup's partial G and S
+  // ---- this workgroup's partial [G | S]: one [M][C + 1] matrix, the row sums in column C
   if (active) {
-    float* const gp = a.gpart + (int64_t)blockIdx.x * a.M * C;
+    float* const gp = a.gpart + (int64_t)blockIdx.x * a.M * (C + 1);
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
 #pragma unroll
@@ -367,33 +366,30 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + 16 * i + 4 * g + r;
-          if (m < a.M) gp[(int64_t)m * C + 16 * ct + li] = G[i][ct][r];
+          if (m < a.M) gp[(int64_t)m * (C + 1) + 16 * ct + li] = G[i][ct][r];
         }
-      float s = S[i];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      float sv = S[i];
+      sv += __shfl_xor(sv, 16);
+      sv += __shfl_xor(sv, 32);
       const int m = m0 + 16 * i + li;
-      if (g == 0 && m < a.mpad) a.spart[(int64_t)blockIdx.x * a.mpad + m] = m < a.M ? s : 0.f;
+      if (g == 0 && m < a.M) gp[(int64_t)m * (C + 1) + C] = sv;
     }
-  } else {
-    for (int m = m0 + lane; m < m0 + K::ROWS && m < a.mpad; m += 64) a.spart[(int64_t)blockIdx.x * a.mpad + m] = 0.f;
   }
 }
 
-// G [M][C], S [M] (already summed over workgroups) -> dW = gamma G + beta S, dgamma = colsum(W o G), dbeta = W^T S.
+// [G | S] (already summed over workgroups; row stride C + 1) -> dW = gamma G + beta S, dgamma = colsum(W o G), dbeta = W^T S.
 // One block per 32 columns, 8 row phases (the matrices are a few hundred KB).
-__global__ __launch_bounds__(256) void bt_finish_kernel(const float* __restrict__ Gs, const float* __restrict__ Ss,
-                                                        const float* __restrict__ w, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ dw,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-                                                        int accumulate) {
+__global__ __launch_bounds__(256) void bt_finish_kernel(const float* __restrict__ GS, const float* __restrict__ w,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ dw, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int M, int C, int accumulate) {
   __shared__ float sg[8][32], sb[8][32];
   const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
   float ag = 0.f, ab = 0.f;
   if (c < C) {
     const float gc = gamma[c], bc = beta ? beta[c] : 0.f;
     for (int m = ph; m < M; m += 8) {
-      const float gg = Gs[(int64_t)m * C + c], ss = Ss[m], ww = w[(int64_t)m * C + c];
+      const float gg = GS[(int64_t)m * (C + 1) + c], ss = GS[(int64_t)m * (C + 1) + C], ww = w[(int64_t)m * C + c];
       float* o = dw + (int64_t)m * C + c;
       *o = (accumulate ? *o : 0.f) + gc * gg + bc * ss;
       ag += ww * gg;
@@ -440,13 +436,12 @@ bool bwd_tail_pays(int M, int C) {
   const char* e = getenv("MI_BT_WIDE");                                 // A/B switch, read per call: 0 keeps the 4-fragment form off
   return !(C == 96 && p.MPW == 4) || !(e && atoi(e) == 0);
 }
-// partial G / S per workgroup, their sums, and the two-stage row reduction's scratch
+// partial [G | S] per workgroup, its sum, and the two-stage row reduction's scratch
 size_t bwd_tail_workspace(int M, int C) {
   BtPlan p;
   if (!bt_plan(M, C, &p)) return 0;
-  const size_t mc = (size_t)M * C;
-  return align_up((size_t)p.grid * mc * 4, 256) + align_up((size_t)p.grid * p.mpad * 4, 256) + align_up(mc * 4, 256) +
-         align_up((size_t)p.mpad * 4, 256) + align_up((size_t)REDUCE_GROUPS * (mc > (size_t)p.mpad ? mc : p.mpad) * 4, 256);
+  const size_t mc = (size_t)M * (C + 1);
+  return align_up((size_t)p.grid * mc * 4, 256) + align_up(mc * 4, 256) + align_up((size_t)REDUCE_GROUPS * mc * 4, 256);
 }
 
 template <int C, int NW, int MPW>
@@ -471,16 +466,14 @@ int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dre
   MI_CHECK_ARG(dy && x && mean && rstd && w && gamma && dx && dw && dgamma && ws, "bwd_tail: null pointer");
   MI_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && (!dres || aligned16(dres)) && aligned16(mean) && aligned16(rstd),
                "bwd_tail: operands must be 16-byte aligned");
-  const size_t mc = (size_t)M * C;
+  const size_t mc = (size_t)M * (C + 1);
   Carver cv(ws);
   float* gpart = cv.take<float>((size_t)p.grid * mc * 4);
-  float* spart = cv.take<float>((size_t)p.grid * p.mpad * 4);
   float* gsum = cv.take<float>(mc * 4);
-  float* ssum = cv.take<float>((size_t)p.mpad * 4);
-  float* tmp = cv.take<float>((size_t)REDUCE_GROUPS * (mc > (size_t)p.mpad ? mc : p.mpad) * 4);
+  float* tmp = cv.take<float>((size_t)REDUCE_GROUPS * mc * 4);
   BtArgs a;
   a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dres = (const bf16*)dres; a.mean = mean; a.rstd = rstd; a.w = w;
-  a.gamma = gamma; a.dx = (bf16*)dx; a.gpart = gpart; a.spart = spart; a.M = M; a.mpad = p.mpad; a.N = N;
+  a.gamma = gamma; a.dx = (bf16*)dx; a.gpart = gpart; a.M = M; a.mpad = p.mpad; a.N = N;
   a.tiles_per_image = (int)(N / 64); a.ntiles = B * a.tiles_per_image;
   { const char* e = getenv("MI_BT_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const int grid = a.ntiles < p.grid ? a.ntiles : p.grid;
@@ -493,11 +486,10 @@ int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dre
     else MI_TRY((bt_launch<48, 4, 3>(a, grid, st)));
   }
   MI_TRY(launch_reduce_rows(gpart, gsum, grid, (int64_t)mc, (int64_t)mc, 0, 1.0f, st, tmp));
-  MI_TRY(launch_reduce_rows(spart, ssum, grid, p.mpad, p.mpad, 0, 1.0f, st, tmp));
   {
     ProfScope ps(st, K_BWD_TAIL_FIN, 4.0 * mc * 4, 4.0 * mc);
-    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, gsum, ssum, w, gamma, beta, dw, dgamma, dbeta, M,
-                       C, accumulate);
+    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, gsum, w, gamma, beta, dw, dgamma, dbeta, M, C,
+                       accumulate);
     MI_LAUNCH_CHECK();
   }
   return MI_OK;
