@@ -21,7 +21,8 @@
 //     wave-private patch) and adds its partial tile into a shared fp32 LDS accumulator with ds_add_f32;
 //   * after a barrier all lanes run the LayerNorm backward on the accumulator (8 or 4 lanes per pixel), transpose the result
 //     through LDS and store 128-byte rows of dx.
-// The next tile's dY rows, x, dres and statistics are in flight (registers) while a tile is computed.
+// The next tile's first dY half, x, dres and statistics are in flight while a tile is computed, and the LayerNorm phase and
+// store of tile i-1 run inside tile i behind the request for its second dY half (software pipeline across tiles).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -251,18 +252,73 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
+  // LayerNorm backward on a finished dxn tile (LPP lanes per pixel, channels sub + LPP j), result into the dres tile in place
+  auto ln_phase = [&](const bf16* xh, bf16* dr, float rstd_p) {
+    if (a.dbg & 8) return;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int px = tt / LPP, sub = tt % LPP;
+    // swizzled slot of (c = sub + LPP j, px): the chunk term of c splits into a lane part (sub/2) and a constant part (LPP j / 2)
+    constexpr int NVAR = 16 / LPP;                                      // distinct constant parts: LPP 8 -> {0,4}, LPP 4 -> {0,2,4,6}
+    int base[NVAR];
+#pragma unroll
+    for (int v = 0; v < NVAR; ++v) base[v] = sub * 64 + ((((px >> 3) ^ (sub >> 1) ^ ((LPP * v) >> 1)) & 7) << 3) + (px & 7);
+    const short* xs = reinterpret_cast<const short*>(xh);
+    short* ds = reinterpret_cast<short*>(dr);
+    const float* const ap = &acc[sub * XS + px];
+    float gv[CPL], xv[CPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      gv[j] = ap[LPP * j * XS];                                         // g = gamma dxn (gamma rides in the W^T fragments)
+      xv[j] = bf_s(xs[base[j % NVAR] + LPP * j * 64]);
+      s1 += gv[j];
+      s2 += gv[j] * xv[j];
+    }
+#pragma unroll
+    for (int o = 1; o < LPP; o <<= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      short* const slot = ds + base[j % NVAR] + LPP * j * 64;
+      *slot = bf_bits(rstd_p * (gv[j] - m1 - xv[j] * m2) + bf_s(*slot));
+    }
+  };
+  auto store_phase = [&](const bf16* dr, int b, int p0) {
+    if (a.dbg & 16) return;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int c0 = tt >> 4, q = tt & 15;                                // rows c0 + (NT/16) i: their swizzle term equals that of c0
+    static_assert((NT / 32) % 8 == 0, "row step of the store loop must keep the swizzle term");
+    const bf16* src = dr + c0 * 64 + ((((q >> 1) ^ (c0 >> 1)) & 7) << 3) + 4 * (q & 1);
+    bf16* const ob = a.dx + (int64_t)b * C * a.N + p0 + (unsigned)c0 * un + 4u * q;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+      *reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un) = *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64);
+  };
+
+  // Tile loop, software-pipelined across tiles: the LayerNorm phase and the dx store of tile i-1 run inside tile i, between the
+  // request for the second half of tile i's dY rows and its first use - the only place where a load had no lead.  (Not in the
+  // 4-fragment form: the pipeline's carried state tips it over the register limit; it loses 7 % pipelined.)
+  constexpr bool PIPE = MPW != 4;
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
     if (active) issue_dy(tile, 0);
     issue_x(tile, 0);
   }
   __syncthreads();
-  int buf = 0;
+  int buf = 0, pb = 0, pp0 = 0;
+  bool have_prev = false;
+  float rstd_prev = 0.f;
   for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
     const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64;
     const int nxt = tile + gridDim.x;
     bf16* const xh = reinterpret_cast<bf16*>(lds + K::OFF_XH + buf * K::TILE_B);
     bf16* const dr = reinterpret_cast<bf16*>(lds + K::OFF_DR + buf * K::TILE_B);
+    bf16* const xh_prev = reinterpret_cast<bf16*>(lds + K::OFF_XH + (buf ^ 1) * K::TILE_B);
+    bf16* const dr_prev = reinterpret_cast<bf16*>(lds + K::OFF_DR + (buf ^ 1) * K::TILE_B);
     // ---- this wave's DMA pieces and dY half have landed: dY -> patch, x -> xh = (x - mean) rstd in place
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (active) stage_dy(0);
@@ -288,7 +344,14 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     const float rstd_p = st[64 + t / LPP];                              // read before the next tile's statistics are requested
     __syncthreads();
     if (active) issue_dy(tile, 1);
-    if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
+    if constexpr (PIPE) {
+      // ---- tile i-1: LayerNorm backward, transpose through its dres tile, store dx
+      if (have_prev) ln_phase(xh_prev, dr_prev, rstd_prev);
+      __syncthreads();
+      if (have_prev) store_phase(dr_prev, pb, pp0);
+    } else {
+      if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
+    }
     if (active && !(a.dbg & 32)) {
       wgrad_half(0, xh);
       stage_dy(1);
@@ -296,11 +359,12 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       if (nxt < a.ntiles) issue_dy(nxt, 0);
       wgrad_half(1, xh);
     }
-    // (rolled for the 4-fragment form: unrolled, its eight copies push that kernel from 4 to 13 spilled registers)
     auto step = [&](int sstep) {
       if (active && !(a.dbg & 32)) dxn_step(sstep);
       else if (sstep == 0) dxn_zero();
       __syncthreads();
+      // every wave is past the store of tile i-1 now: its x / dres buffers can take tile i+1
+      if (PIPE && sstep == 0 && nxt < a.ntiles) issue_x(nxt, buf ^ 1);
     };
     if constexpr (MPW == 4) {   // (rolled: unrolled, the eight copies push this form from 0 to 13 spilled registers; the
                                 // 3-fragment forms are 4 % faster unrolled)
@@ -310,51 +374,21 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
 #pragma unroll
       for (int sstep = 0; sstep < NW; ++sstep) step(sstep);
     }
-    // ---- LayerNorm backward on the finished dxn tile: LPP lanes per pixel, channels sub + LPP j
-    if (!(a.dbg & 8)) {
-      int tt = t;
-      asm volatile("" : "+v"(tt));
-      const int px = tt / LPP, sub = tt % LPP;
-      // swizzled slot of (c = sub + LPP j, px): the chunk term of c splits into a lane part (sub/2) and a constant part (LPP j / 2)
-      constexpr int NVAR = 16 / LPP;                                    // distinct constant parts: LPP 8 -> {0,4}, LPP 4 -> {0,2,4,6}
-      int base[NVAR];
-#pragma unroll
-      for (int v = 0; v < NVAR; ++v) base[v] = sub * 64 + ((((px >> 3) ^ (sub >> 1) ^ ((LPP * v) >> 1)) & 7) << 3) + (px & 7);
-      const short* xs = reinterpret_cast<const short*>(xh);
-      short* ds = reinterpret_cast<short*>(dr);
-      float* const ap = &acc[sub * XS + px];
-      float gv[CPL], xv[CPL], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        gv[j] = ap[LPP * j * XS];                                       // g = gamma dxn (gamma rides in the W^T fragments)
-        xv[j] = bf_s(xs[base[j % NVAR] + LPP * j * 64]);
-        s1 += gv[j];
-        s2 += gv[j] * xv[j];
-      }
-#pragma unroll
-      for (int o = 1; o < LPP; o <<= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-      }
-      const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        short* const slot = ds + base[j % NVAR] + LPP * j * 64;
-        *slot = bf_bits(rstd_p * (gv[j] - m1 - xv[j] * m2) + bf_s(*slot));
-      }
+    if constexpr (PIPE) {
+      have_prev = true; pb = b; pp0 = p0; rstd_prev = rstd_p;
+    } else {
+      ln_phase(xh, dr, rstd_p);
+      __syncthreads();
+      store_phase(dr, b, p0);
     }
+  }
+  if (PIPE && have_prev) {                                               // the last tile's LayerNorm phase and store
+    const int lb = buf ^ 1;
+    bf16* const xh_l = reinterpret_cast<bf16*>(lds + K::OFF_XH + lb * K::TILE_B);
+    bf16* const dr_l = reinterpret_cast<bf16*>(lds + K::OFF_DR + lb * K::TILE_B);
+    ln_phase(xh_l, dr_l, rstd_prev);
     __syncthreads();
-    if (!(a.dbg & 16)) {
-      int tt = t;
-      asm volatile("" : "+v"(tt));
-      const int c0 = tt >> 4, q = tt & 15;                              // rows c0 + (NT/16) i: their swizzle term equals that of c0
-      static_assert((NT / 32) % 8 == 0, "row step of the store loop must keep the swizzle term");
-      const bf16* src = dr + c0 * 64 + ((((q >> 1) ^ (c0 >> 1)) & 7) << 3) + 4 * (q & 1);
-      bf16* const ob = a.dx + (int64_t)b * C * a.N + p0 + (unsigned)c0 * un + 4u * q;
-#pragma unroll
-      for (int i = 0; i < ITEMS; ++i)
-        *reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un) = *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64);
-    }
+    store_phase(dr_l, pb, pp0);
   }
   // ---- this workgroup's partial [G | S]: one [M][C + 1] matrix, the row sums in column C
   if (active) {
@@ -378,17 +412,18 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
 }
 
 // [G | S] (already summed over workgroups; row stride C + 1) -> dW = gamma G + beta S, dgamma = colsum(W o G), dbeta = W^T S.
-// One block per 32 columns, 8 row phases (the matrices are a few hundred KB).
-__global__ __launch_bounds__(256) void bt_finish_kernel(const float* __restrict__ GS, const float* __restrict__ w,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ dw, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int M, int C, int accumulate) {
-  __shared__ float sg[8][32], sb[8][32];
+// One block of 1024 threads per 32 columns: 32 row phases, so a thread walks M / 32 rows (with 8 phases the dependent
+// read-modify-write of dW made this 27 us per launch).
+__global__ __launch_bounds__(1024) void bt_finish_kernel(const float* __restrict__ GS, const float* __restrict__ w,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ dw, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int M, int C, int accumulate) {
+  __shared__ float sg[32][33], sb[32][33];
   const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
   float ag = 0.f, ab = 0.f;
   if (c < C) {
     const float gc = gamma[c], bc = beta ? beta[c] : 0.f;
-    for (int m = ph; m < M; m += 8) {
+    for (int m = ph; m < M; m += 32) {
       const float gg = GS[(int64_t)m * (C + 1) + c], ss = GS[(int64_t)m * (C + 1) + C], ww = w[(int64_t)m * C + c];
       float* o = dw + (int64_t)m * C + c;
       *o = (accumulate ? *o : 0.f) + gc * gg + bc * ss;
@@ -402,7 +437,7 @@ __global__ __launch_bounds__(256) void bt_finish_kernel(const float* __restrict_
   if (ph == 0 && c < C) {
     float tg = 0.f, tb = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { tg += sg[k][cx]; tb += sb[k][cx]; }
+    for (int k = 0; k < 32; ++k) { tg += sg[k][cx]; tb += sb[k][cx]; }
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + tg;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + tb;
   }
@@ -488,7 +523,7 @@ int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dre
   MI_TRY(launch_reduce_rows(gpart, gsum, grid, (int64_t)mc, (int64_t)mc, 0, 1.0f, st, tmp));
   {
     ProfScope ps(st, K_BWD_TAIL_FIN, 4.0 * mc * 4, 4.0 * mc);
-    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, gsum, w, gamma, beta, dw, dgamma, dbeta, M, C,
+    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, gsum, w, gamma, beta, dw, dgamma, dbeta, M, C,
                        accumulate);
     MI_LAUNCH_CHECK();
   }
