@@ -62,7 +62,7 @@ struct BtCfg {
   static constexpr int PROWS = 32 * KS;          // patch rows (rows past ROWS stay zero)
   static constexpr int NT = 64 * NW;
   static constexpr int XS = 68;                  // fp32 stride of the dxn accumulator [channel][64 pixels + pad]
-  static constexpr int TPS = 4 * (C / 16) / NW;  // 16 x 16 output fragments per slice of the rotating reduction
+
   static constexpr int LPP = NT / 64;            // lanes per pixel in the LayerNorm-backward phase
   static constexpr int CPL = C / LPP;            // channels per lane there
   static constexpr int ITEMS = C * 16 / NT;      // (channel row, 4-pixel quad) items per lane when dx is stored
@@ -78,7 +78,7 @@ struct BtCfg {
   static constexpr int BYTES = OFF_ST + NW * 512;
   static_assert(C % 16 == 0 && (LPP == 4 || LPP == 8) && C % LPP == 0 && (C * 16) % NT == 0 && (2 * XP) % NW == 0,
                 "unsupported shape");
-  static_assert((NW == 8 && C == 96) || (NW == 4 && C == 48), "slice map of the rotating reduction: 3 fragments per slice");
+  static_assert(C / 16 <= NW, "one wave per 16-channel output tile of the dxn product");
   static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -105,19 +105,21 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
 
   for (int i = lane; i < K::PATCH_E / 8; i += 64) reinterpret_cast<u32x4*>(patch)[i] = zero4;
 
-  // (W diag(gamma))^T fragments (B operand of the dxn product): column c = 16 ct + li, k slots = this wave's rows in the
-  // patch's slot order
-  s16x8 wt[CT][KS];
+  // (W diag(gamma))^T fragments (B operand of the dxn product) of THIS wave's channel tile, ct = wv (waves past CT take no part
+  // in the product): column c = 16 wv + li, k slots = the rows of owner wave o in its patch's slot order.
+  const bool dxn_wave = wv < CT;                                        // wave-uniform
+  s16x8 wt[NW][KS];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+  for (int o = 0; o < NW; ++o)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int ml = 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4), m = m0 + ml;
-        const int mc = (ml < K::ROWS && m < a.M) ? m : 0;
-        const float v = a.w[mc * C + 16 * ct + li] * a.gamma[16 * ct + li];     // gamma folded in: the product is g = gamma dxn
-        wt[ct][ks][j] = (ml < K::ROWS && m < a.M) ? bf_bits(v) : (short)0;
+        const int ml = 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4), m = o * K::ROWS + ml;
+        const bool ok = dxn_wave && ml < K::ROWS && m < a.M;
+        const int cc = dxn_wave ? 16 * wv + li : 0;
+        const float v = a.w[(ok ? m : 0) * C + cc] * a.gamma[cc];       // gamma folded in: the product is g = gamma dxn
+        wt[o][ks][j] = ok ? bf_bits(v) : (short)0;
       }
   f32x4 G[MPW][CT];
   float S[MPW];
@@ -204,52 +206,39 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       }
     }
   };
-  // dxn = W^T dY needs the sum over ALL rows, i.e. over the waves.  (ds_add_f32 into a shared tile measured ~190 cycles per
-  // wave-instruction on gfx950 - lane-serialised - and made the kernel 8x slower than everything else in it.)  Instead the
-  // 64 x C output tile is cut into NW slices of three 16 x 16 fragments; in step s wave w owns slice (w + s) mod NW: it loads
-  // the running sum as the MFMA accumulator input (step 0: zero), adds its rows' contribution and stores it back.  A barrier
-  // separates steps.
-  auto dxn_step = [&](int s) {
+  // dxn = W^T dY needs the sum over ALL rows, i.e. over every wave's dY.  Two schemes lost: ds_add_f32 of per-wave partials into
+  // a shared tile (the LDS float atomic measured ~190 cycles per wave-instruction on gfx950 - lane-serialised - 8x slower than
+  // the rest of the kernel together) and a rotating read-add-write of slices (NW barriers per tile, 30 % of the kernel).  Now
+  // wave w < CT owns output channels 16w..16w+15 for all 64 pixels: once every wave has staged its rows (one barrier) it walks
+  // ALL patches - transposed reads of the others' rows, its own W^T column tile in registers - and stores the finished tile.
+  auto dxn_tile = [&]() {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int li_ = ln & 15, g_ = ln >> 4, qq_ = li_ >> 2, pp_ = li_ & 3;
-    const int j = (wv + s) & (NW - 1);                                  // wave-uniform
-    const int nt = NW == 8 ? (j >> 1) : j;
-    const bool skip = (a.dbg & 2) != 0;
-    const bf16* tr0 = &patch[(4 * g_ + qq_) * PS + 16 * nt + 4 * pp_];
-    s16x4 lo[KS], hi[KS];
-    if (!skip) {
+    f32x4 d[4];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        lo[ks] = tr_b16(tr0 + (32 * ks) * PS);
-        hi[ks] = tr_b16(tr0 + (32 * ks + 16) * PS);
+    for (int nt = 0; nt < 4; ++nt) d[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16* tr0 = reinterpret_cast<const bf16*>(lds) + (4 * g_ + qq_) * PS + 4 * pp_;
+#pragma unroll
+    for (int o = 0; o < NW; ++o) {
+      if (o * K::ROWS < a.M) {                                           // (uniform) owners past M hold no rows
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s16x4 lo[4], hi[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            lo[nt] = tr_b16(tr0 + o * K::PATCH_E + (32 * ks) * PS + 16 * nt);
+            hi[nt] = tr_b16(tr0 + o * K::PATCH_E + (32 * ks + 16) * PS + 16 * nt);
+          }
+          lds_wait(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) d[nt] = mfma32(cat8(lo[nt], hi[nt]), wt[o][ks], d[nt]);
+        }
       }
     }
-    float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];   // 4 consecutive pixels of one channel
-    f32x4 d[3];
+    float* const ap0 = &acc[(16 * wv + li_) * XS + 4 * g_];              // 4 consecutive pixels of channel 16 wv + li
 #pragma unroll
-    for (int u = 0; u < 3; ++u) d[u] = s == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ap0 + 16 * u * XS);   // (s is uniform)
-    if (skip) return;
-    if (KS == 1) lds_wait(lo[0], hi[0]);
-    else lds_wait(lo[0], hi[0], lo[KS - 1], hi[KS - 1]);
-    auto run = [&](auto ct0) {
-      constexpr int CT0 = decltype(ct0)::value;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) d[u] = mfma32(cat8(lo[ks], hi[ks]), wt[CT0 + u][ks], d[u]);
-        *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = d[u];
-      }
-    };
-    if (NW == 8 && (j & 1)) run(std::integral_constant<int, (CT > 3 ? 3 : 0)>{});
-    else run(std::integral_constant<int, 0>{});
-  };
-  // a wave without rows owns a slice in step 0 all the same: it stores the zeros the others then add to
-  auto dxn_zero = [&]() {
-    const int j = wv, nt = NW == 8 ? (j >> 1) : j, li_ = lane & 15, g_ = lane >> 4;
-    float* const ap0 = &acc[((NW == 8 && (j & 1)) ? 48 + li_ : li_) * XS + 16 * nt + 4 * g_];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(ap0 + 16 * u * XS) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(ap0 + 16 * nt) = d[nt];
   };
 
   // LayerNorm backward on a finished dxn tile (LPP lanes per pixel, channels sub + LPP j), result into the dres tile in place
@@ -359,21 +348,11 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       if (nxt < a.ntiles) issue_dy(nxt, 0);
       wgrad_half(1, xh);
     }
-    auto step = [&](int sstep) {
-      if (active && !(a.dbg & 32)) dxn_step(sstep);
-      else if (sstep == 0) dxn_zero();
-      __syncthreads();
-      // every wave is past the store of tile i-1 now: its x / dres buffers can take tile i+1
-      if (PIPE && sstep == 0 && nxt < a.ntiles) issue_x(nxt, buf ^ 1);
-    };
-    if constexpr (MPW == 4) {   // (rolled: unrolled, the eight copies push this form from 0 to 13 spilled registers; the
-                                // 3-fragment forms are 4 % faster unrolled)
-#pragma unroll 1
-      for (int sstep = 0; sstep < NW; ++sstep) step(sstep);
-    } else {
-#pragma unroll
-      for (int sstep = 0; sstep < NW; ++sstep) step(sstep);
-    }
+    __syncthreads();                                                     // every wave's dY rows of this tile are in LDS
+    // every wave is past the store of tile i-1 now too: its x / dres buffers can take tile i+1
+    if (PIPE && nxt < a.ntiles) issue_x(nxt, buf ^ 1);
+    if (dxn_wave && !(a.dbg & 34)) dxn_tile();
+    __syncthreads();                                                     // dxn tile complete; the patches may be overwritten
     if constexpr (PIPE) {
       have_prev = true; pb = b; pp0 = p0; rstd_prev = rstd_p;
     } else {
