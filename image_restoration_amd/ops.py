@@ -47,11 +47,31 @@ def _f32(t: Optional[Tensor], what: str) -> Optional[Tensor]:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object: 9 us per call)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _blob(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_WS_CACHE: dict = {}
+_WS_CACHE_ON = os.environ.get("MI_WS_CACHE", "1") != "0"
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    """Scratch for ONE library call.  Calls are stream-ordered and a workspace is dead when its call returns, so one grow-only
+    buffer per device serves them all (a launch-bound step made ~2000 allocator calls for these; MI_WS_CACHE=0: per-call blobs)."""
+    n = max(int(nbytes), 256)
+    if not _WS_CACHE_ON:
+        return torch.empty(n, dtype=torch.uint8, device=device)
+    key = device.index
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < n:
+        buf = None
+        _WS_CACHE.pop(key, None)                       # release the old one first
+        buf = _WS_CACHE[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return buf
 
 
 # ----------------------------------------------------------------------------- LayerNorm
@@ -74,7 +94,7 @@ def ln_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dres: O
     _gpu(dy, x, w, mean, rstd, dres, dw, db)
     B, Cc, H, W = x.shape
     dx = torch.empty_like(x)
-    ws = _blob(L.lib().mi_ln_bwd_workspace(B, Cc, H * W), x.device)
+    ws = _ws(L.lib().mi_ln_bwd_workspace(B, Cc, H * W), x.device)
     L.check(L.lib().mi_ln_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), B, Cc, H * W,
                               int(with_bias), int(accumulate), _dt(x), _p(ws), _stream()), "ln_bwd")
     return dx
@@ -108,7 +128,7 @@ def dwconv_bwd(dy: Tensor, x: Tensor, w: Tensor, has_bias: bool):
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_bias else None
-    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, Cc, H, W, ks), x.device)
+    ws = _ws(L.lib().mi_dwconv_bwd_workspace(B, Cc, H, W, ks), x.device)
     L.check(L.lib().mi_dwconv_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Cc, H, W, ks, 0, _dt(x), _p(ws),
                                   _stream()), "dwconv_bwd")
     return dx, dw, db
@@ -121,7 +141,7 @@ def dwconv_gate_bwd(dg: Tensor, y: Tensor, x: Tensor, w: Tensor, has_bias: bool)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     db = torch.empty(C2, dtype=torch.float32, device=x.device) if has_bias else None
-    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
+    ws = _ws(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
     L.check(L.lib().mi_dwconv_gate_bwd(_p(dg), _p(y), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, C2, H, W, ks, 0, _dt(x),
                                        _p(ws), _stream()), "dwconv_gate_bwd")
     return dx, dw, db
@@ -140,7 +160,7 @@ def dwconv_gate_bwd_recompute(dg: Tensor, x: Tensor, w: Tensor, bias: Optional[T
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     db = torch.empty(C2, dtype=torch.float32, device=x.device) if bias is not None else None
-    ws = _blob(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
+    ws = _ws(L.lib().mi_dwconv_bwd_workspace(B, C2, H, W, ks), x.device)
     L.check(L.lib().mi_dwconv_gate_bwd_recompute(_p(dg), _p(x), _p(w), _p(bias), _p(dx), _p(dw), _p(db), B, C2, H, W, ks, 0,
                                                  _dt(x), _p(ws), _stream()), "dwconv_gate_bwd_recompute")
     return dx, dw, db
@@ -175,7 +195,7 @@ def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
 
 def pw_gemm_desc(d: "L.PwDesc", device) -> None:
     """Run one mi_pw_gemm call described by ``d`` (allocates its weight-pack workspace)."""
-    ws = _blob(L.lib().mi_pw_gemm_workspace(C.byref(d)), device)
+    ws = _ws(L.lib().mi_pw_gemm_workspace(C.byref(d)), device)
     L.check(L.lib().mi_pw_gemm(C.byref(d), _p(ws), _stream()), "pw_gemm")
 
 
@@ -195,7 +215,7 @@ def gram(a: Tensor, b: Tensor, groups: int = 1, sum_batch: bool = False, want_su
     d.n, d.batch, d.groups, d.dtype = N, B, groups, _dt(a)
     d.sum_batch, d.accumulate = int(sum_batch), 0
     d.out, d.out_ld, d.out_zs, d.sumsq = _p(out), mb, ma * mb, _p(ss)
-    ws = _blob(L.lib().mi_gram_workspace(C.byref(d)), a.device)
+    ws = _ws(L.lib().mi_gram_workspace(C.byref(d)), a.device)
     L.check(L.lib().mi_gram(C.byref(d), _p(ws), _stream()), "gram")
     return (out, ss) if want_sumsq else out
 
@@ -249,7 +269,7 @@ def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: 
     lib = L.lib()
     out = torch.empty_like(x)
     saved = _blob(lib.mi_mdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
-    ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
+    ws = _ws(lib.mi_mdta_workspace(C.byref(s)), x.device)
     pp = _mdta_params(params)
     if ln is None:
         L.check(lib.mi_mdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
@@ -296,12 +316,12 @@ def mdta_bwd(x: Tensor, dout: Tensor, params: MdtaParamsT, heads: int, saved: Te
         _f32(t, "MDTA gradient")
     gg = L.MdtaGrads(*[_p(t) for t in grads], int(accumulate))
     if ln is None:
-        ws = _blob(lib.mi_mdta_workspace(C.byref(s)), x.device)
+        ws = _ws(lib.mi_mdta_workspace(C.byref(s)), x.device)
         L.check(lib.mi_mdta_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
                 "mdta_bwd")
     else:
         lt = _ln_tail(ln, x)
-        ws = _blob(lib.mi_mdta_bwd_ln_workspace(C.byref(s)), x.device)
+        ws = _ws(lib.mi_mdta_bwd_ln_workspace(C.byref(s)), x.device)
         L.check(lib.mi_mdta_bwd_ln(C.byref(s), C.byref(pp), C.byref(lt), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved),
                                    _p(ws), _stream()), "mdta_bwd_ln")
     return dx
@@ -324,7 +344,7 @@ def xmdta_fwd(x: Tensor, y: Tensor, residual: Optional[Tensor], params: Sequence
     lib = L.lib()
     out = torch.empty_like(x)
     saved = _blob(lib.mi_xmdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
-    ws = _blob(lib.mi_xmdta_workspace(C.byref(s)), x.device)
+    ws = _ws(lib.mi_xmdta_workspace(C.byref(s)), x.device)
     pp = L.XmdtaParams(*[_p(t) for t in params])
     L.check(lib.mi_xmdta_fwd(C.byref(s), C.byref(pp), _p(x), _p(y), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
             "xmdta_fwd")
@@ -337,7 +357,7 @@ def xmdta_bwd(x: Tensor, y: Tensor, dout: Tensor, params: Sequence[Optional[Tens
     s = _xmdta_shape(x, heads, params[3].shape[-1], params[7].shape[-1])
     lib = L.lib()
     dx, dy = torch.empty_like(x), torch.empty_like(y)
-    ws = _blob(lib.mi_xmdta_workspace(C.byref(s)), x.device)
+    ws = _ws(lib.mi_xmdta_workspace(C.byref(s)), x.device)
     pp = L.XmdtaParams(*[_p(t) for t in params])
     for t in grads:
         _f32(t, "cross-MDTA gradient")
@@ -371,7 +391,7 @@ def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_sa
     lib = L.lib()
     out = torch.empty_like(x)
     saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(s)), x.device) if need_saved else None
-    ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+    ws = _ws(lib.mi_gdfn_workspace(C.byref(s)), x.device)
     pp = L.GdfnParams(*[_p(t) for t in params])
     if ln is None:
         L.check(lib.mi_gdfn_fwd(C.byref(s), C.byref(pp), _p(x), _p(residual), _p(out), _p(saved), _p(ws), _stream()),
@@ -410,12 +430,12 @@ def gdfn_bwd(x: Tensor, dout: Tensor, params: GdfnParamsT, saved: Tensor, grads:
         _f32(t, "GDFN gradient")
     gg = L.GdfnGrads(*[_p(t) for t in grads], int(accumulate))
     if ln is None:
-        ws = _blob(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+        ws = _ws(lib.mi_gdfn_workspace(C.byref(s)), x.device)
         L.check(lib.mi_gdfn_bwd(C.byref(s), C.byref(pp), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved), _p(ws), _stream()),
                 "gdfn_bwd")
     else:
         lt = _ln_tail(ln, x)
-        ws = _blob(lib.mi_gdfn_bwd_ln_workspace(C.byref(s)), x.device)
+        ws = _ws(lib.mi_gdfn_bwd_ln_workspace(C.byref(s)), x.device)
         L.check(lib.mi_gdfn_bwd_ln(C.byref(s), C.byref(pp), C.byref(lt), _p(x), _p(dout), _p(dx), C.byref(gg), _p(saved),
                                    _p(ws), _stream()), "gdfn_bwd_ln")
     return dx
@@ -433,7 +453,7 @@ def bwd_tail(dy: Tensor, x: Tensor, dres: Optional[Tensor], mean: Tensor, rstd: 
     M = dy.shape[1]
     dx = torch.empty_like(x)
     lib = L.lib()
-    ws = _blob(lib.mi_bwd_tail_workspace(M, Cc), x.device)
+    ws = _ws(lib.mi_bwd_tail_workspace(M, Cc), x.device)
     L.check(lib.mi_bwd_tail(_p(dy), M, _p(x), Cc, _p(dres), _p(mean), _p(rstd), _p(w), _p(gamma), _p(beta), _p(dx), _p(dw),
                             _p(dgamma), _p(dbeta), B, H * W, int(accumulate), _dt(x), _p(ws), _stream()), "bwd_tail")
     return dx
@@ -522,7 +542,7 @@ def rows_dot(g: Tensor, src: Tensor, idx: Tensor) -> Tensor:
     if n == 0:
         return out
     row = src[0].numel()
-    ws = _blob(L.lib().mi_rows_dot_workspace(n, row), src.device)
+    ws = _ws(L.lib().mi_rows_dot_workspace(n, row), src.device)
     L.check(L.lib().mi_rows_dot(_p(_f32(g, "g")), _p(src), _p(idx), _p(out), n, row, _dt(src), _p(ws), _stream()), "rows_dot")
     return out
 

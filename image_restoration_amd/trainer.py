@@ -74,6 +74,7 @@ class FlatTrainer:
                 lo = min(self.offsets[id(p)][0] for p in ps)
                 hi = max(self.offsets[id(p)][0] + (self.offsets[id(p)][1] + ALIGN - 1) // ALIGN * ALIGN for p in ps)
                 self.stages.append((uname, unit, lo, hi))
+        self._param_lists: dict = {}
         self.overlap = overlap and self.world > 1
         self._exec_order: List[int] = []
         self._reduced: set = set()
@@ -168,8 +169,13 @@ class FlatTrainer:
         self._bwd_started = False
 
     def _fold_autograd_grads(self, module: nn.Module) -> None:
-        """Glue layers that still run as PyTorch ops deliver .grad through autograd: add it into main_grad."""
-        for p in module.parameters():
+        """Glue layers that still run as PyTorch ops deliver .grad through autograd: add it into main_grad.
+        (The parameter list of a module is cached: walking the module tree of MoCE-IR base every step cost 5 ms of host
+        time in a launch-bound step.)"""
+        ps = self._param_lists.get(id(module))
+        if ps is None:
+            ps = self._param_lists[id(module)] = [p for p in module.parameters() if p.requires_grad]
+        for p in ps:
             if p.grad is not None:
                 p.main_grad.add_(p.grad)
                 p.grad = None
