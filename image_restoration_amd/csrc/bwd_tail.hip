@@ -94,7 +94,9 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   constexpr int CT = K::CT, KS = K::KS, PS = BT_PS, XS = K::XS, NT = K::NT, LPP = K::LPP, CPL = K::CPL, ITEMS = K::ITEMS;
   constexpr int XP = K::XP, PPW = K::PPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);               // wave index in a scalar register: everything derived from
+                                                                        // it (row range, patch, DMA pieces, channel tile) is scalar too
   bf16* const patch = reinterpret_cast<bf16*>(lds) + wv * K::PATCH_E;
   float* const acc = reinterpret_cast<float*>(lds + K::OFF_ACC);
   float* const st = reinterpret_cast<float*>(lds + K::OFF_ST + wv * 512);   // this wave's copy of mean[64], rstd[64]
@@ -136,12 +138,15 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   const int rl = lane >> 2;                                            // row inside a 16-row fragment, 64 bytes (4 lanes) per row
   auto issue_dy = [&](int tile, int h) {
     const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64 + 32 * h;
+    int ln = lane;                                                      // (opaque copy: see wgrad_half)
+    asm volatile("" : "+v"(ln));
+    const int rl = ln >> 2;
 #pragma unroll
     for (int j = 0; j < MPW; ++j) {
       const int lim = a.M - 1 - (m0 + 16 * j);                          // last valid row of this fragment (wave-uniform)
       if (lim >= 0) {
         const bf16* base = a.dy + ((int64_t)b * a.M + m0 + 16 * j) * a.N + p0;
-        const unsigned off = (unsigned)(rl < lim ? rl : lim) * un + 8u * (lane & 3);
+        const unsigned off = (unsigned)(rl < lim ? rl : lim) * un + 8u * (ln & 3);
         R[j] = *reinterpret_cast<const u32x4*>(base + off);
       }
     }
@@ -157,18 +162,20 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   auto issue_x = [&](int tile, int nb) {
     const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64;
     const int64_t img = (int64_t)b * C * a.N + p0;
+    int ln = lane;                                                      // (opaque copy: hoisted, these per-lane address terms
+    asm volatile("" : "+v"(ln));                                        //  were spilled and reloaded behind vmcnt(0) waits)
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
       const int pid = wv + NW * k;                                      // wave-uniform
       const bool isx = pid < XP;
-      const int u = isx ? pid : pid - XP, c = 8 * u + (lane >> 3), kk = ((lane & 7) ^ (c >> 1)) & 7;
+      const int u = isx ? pid : pid - XP, c = 8 * u + (ln >> 3), kk = ((ln & 7) ^ (c >> 1)) & 7;
       if (isx || a.dres) {
         const bf16* src = (isx ? a.x : a.dres) + img + (unsigned)c * un + 8u * kk;
         unsigned char* dst = lds + (isx ? K::OFF_XH : K::OFF_DR) + nb * K::TILE_B + u * 1024;
         __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)dst, 16, 0, 0);
       }
     }
-    const int64_t so = (int64_t)b * a.N + p0 + lane;
+    const int64_t so = (int64_t)b * a.N + p0 + ln;
     __builtin_amdgcn_global_load_lds((const void*)(a.mean + so), (lds_ptr)(lds + K::OFF_ST + wv * 512), 4, 0, 0);
     __builtin_amdgcn_global_load_lds((const void*)(a.rstd + so), (lds_ptr)(lds + K::OFF_ST + wv * 512 + 256), 4, 0, 0);
   };
@@ -289,9 +296,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   };
 
   // Tile loop, software-pipelined across tiles: the LayerNorm phase and the dx store of tile i-1 run inside tile i, between the
-  // request for the second half of tile i's dY rows and its first use - the only place where a load had no lead.  (Not in the
-  // 4-fragment form: the pipeline's carried state tips it over the register limit; it loses 7 % pipelined.)
-  constexpr bool PIPE = MPW != 4;
+  // request for the second half of tile i's dY rows and its first use - the only place where a load had no lead.
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
     if (active) issue_dy(tile, 0);
@@ -333,14 +338,10 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     const float rstd_p = st[64 + t / LPP];                              // read before the next tile's statistics are requested
     __syncthreads();
     if (active) issue_dy(tile, 1);
-    if constexpr (PIPE) {
-      // ---- tile i-1: LayerNorm backward, transpose through its dres tile, store dx
-      if (have_prev) ln_phase(xh_prev, dr_prev, rstd_prev);
-      __syncthreads();
-      if (have_prev) store_phase(dr_prev, pb, pp0);
-    } else {
-      if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
-    }
+    // ---- tile i-1: LayerNorm backward, transpose through its dres tile, store dx
+    if (have_prev) ln_phase(xh_prev, dr_prev, rstd_prev);
+    __syncthreads();
+    if (have_prev) store_phase(dr_prev, pb, pp0);
     if (active && !(a.dbg & 32)) {
       wgrad_half(0, xh);
       stage_dy(1);
@@ -350,18 +351,12 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     }
     __syncthreads();                                                     // every wave's dY rows of this tile are in LDS
     // every wave is past the store of tile i-1 now too: its x / dres buffers can take tile i+1
-    if (PIPE && nxt < a.ntiles) issue_x(nxt, buf ^ 1);
+    if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
     if (dxn_wave && !(a.dbg & 34)) dxn_tile();
     __syncthreads();                                                     // dxn tile complete; the patches may be overwritten
-    if constexpr (PIPE) {
-      have_prev = true; pb = b; pp0 = p0; rstd_prev = rstd_p;
-    } else {
-      ln_phase(xh, dr, rstd_p);
-      __syncthreads();
-      store_phase(dr, b, p0);
-    }
+    have_prev = true; pb = b; pp0 = p0; rstd_prev = rstd_p;
   }
-  if (PIPE && have_prev) {                                               // the last tile's LayerNorm phase and store
+  if (have_prev) {                                               // the last tile's LayerNorm phase and store
     const int lb = buf ^ 1;
     bf16* const xh_l = reinterpret_cast<bf16*>(lds + K::OFF_XH + lb * K::TILE_B);
     bf16* const dr_l = reinterpret_cast<bf16*>(lds + K::OFF_DR + lb * K::TILE_B);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   __shared__ __attribute__((aligned(16))) T As[TA * AS];
   __shared__ __attribute__((aligned(16))) T Bs[TA * AS];
 
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar wave index)
   const int li = lane & 15, g = lane >> 4;
   const int wr = wv >> 1, wc = wv & 1;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   if (c_end > p.nchunks) c_end = p.nchunks;
 
   u32x4 areg[F], breg[F];
+  // (thread / lane ids below are opaque copies: the per-lane address terms are loop-invariant, and kept across the chunk loop
+  //  they are what lifts this kernel over the 170 registers that allow a third workgroup per CU)
   auto load_rows = [&](const T* base, int row0, int rows, int chunk, u32x4* regs) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int i = 0; i < F; ++i) {
-      const int v = t + 256 * i;
+      const int v = tt + 256 * i;
       const int row = v >> 3, seg = v & 7;
       const int64_t n = (int64_t)chunk * KC + seg * EPV;
       const int r = row0 + row;
@@ -63,9 +67,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
     }
   };
   auto write_rows = [&](T* dst, const u32x4* regs) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int i = 0; i < F; ++i) {
-      const int v = t + 256 * i;
+      const int v = tt + 256 * i;
       const int row = v >> 3, seg = v & 7;
       T* d = dst + row * AS + seg * EPV;
       if constexpr (F32) {  // 136-byte rows: 8-byte aligned only
@@ -118,13 +124,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
             acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
       }
     } else {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const T* ap = &As[(ra + (ln & 15)) * AS + 8 * (ln >> 4)];
+      const T* bp = &Bs[(cb + (ln & 15)) * AS + 8 * (ln >> 4)];
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
         s16x8 av[F], bv[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          av[f] = *reinterpret_cast<const s16x8*>(&As[(ra + 16 * f + li) * AS + 32 * ks + 8 * g]);
-          bv[f] = *reinterpret_cast<const s16x8*>(&Bs[(cb + 16 * f + li) * AS + 32 * ks + 8 * g]);
+          av[f] = *reinterpret_cast<const s16x8*>(ap + 16 * f * AS + 32 * ks);
+          bv[f] = *reinterpret_cast<const s16x8*>(bp + 16 * f * AS + 32 * ks);
           if (SS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256) void gram_stream_kernel(GramK p, int steps_per
   using T = bf16;
   __shared__ __attribute__((aligned(16))) f32x4 red[2][FA * FB][64];
   __shared__ float ssm[SS ? 4 : 1][SS ? (FA + FB) * 16 : 1];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar wave index)
   const int li = lane & 15, g = lane >> 4;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
@@ -194,36 +204,32 @@ __global__ __launch_bounds__(256) void gram_stream_kernel(GramK p, int steps_per
   const int s_begin = blockIdx.x * steps_per_block;
   const int s_end = min(s_begin + steps_per_block, nsteps);
 
-  const T* arow[FA];
-  const T* brow[FB];
-  bool aok[FA], bok[FB];
-#pragma unroll
-  for (int f = 0; f < FA; ++f) {
-    const int r = i0 + 16 * f + li;
-    aok[f] = r < p.ma;
-    arow[f] = A + (int64_t)(aok[f] ? r : 0) * p.n + 8 * g;
-  }
-#pragma unroll
-  for (int f = 0; f < FB; ++f) {
-    const int r = j0 + 16 * f + li;
-    bok[f] = r < p.mb;
-    brow[f] = B + (int64_t)(bok[f] ? r : 0) * p.n + 8 * g;
-  }
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // Row addresses are rebuilt for every step from an opaque copy of the lane id: kept across the loop (FA + FB 64-bit pointers
+  // and their validity flags) they cost ~30 registers of a kernel that needs every one for its two steps of loads in flight.
   auto load_step = [&](int s, u32x4 (*av)[2], u32x4 (*bv)[2]) {
-    const int64_t px = (int64_t)s * 64 + 8 * g;          // this lane's first pixel of k-step 0; k-step 1 is 32 further
-    const bool in0 = s < s_end && px + 8 <= p.n, in1 = s < s_end && px + 40 <= p.n;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int li_ = ln & 15, g_ = ln >> 4;
+    // 32-bit element offsets from the (uniform) operand bases: one slice is at most rows * n < 2^31 elements (gram_stream_ok)
+    const unsigned px = (unsigned)s * 64u + 8u * g_;     // this lane's first pixel of k-step 0; k-step 1 is 32 further
+    const unsigned un = (unsigned)p.n;
+    const bool in0 = s < s_end && px + 8 <= un, in1 = s < s_end && px + 40 <= un;
 #pragma unroll
     for (int f = 0; f < FA; ++f) {
-      const u32x4* q = reinterpret_cast<const u32x4*>(arow[f] + (int64_t)s * 64);
-      av[f][0] = (aok[f] && in0) ? q[0] : zero4;
-      av[f][1] = (aok[f] && in1) ? q[4] : zero4;
+      const int r = i0 + 16 * f + li_;
+      const bool ok = r < p.ma;
+      const u32x4* q = reinterpret_cast<const u32x4*>(A + ((unsigned)(ok ? r : 0) * un + px));
+      av[f][0] = (ok && in0) ? q[0] : zero4;
+      av[f][1] = (ok && in1) ? q[4] : zero4;
     }
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
-      const u32x4* q = reinterpret_cast<const u32x4*>(brow[f] + (int64_t)s * 64);
-      bv[f][0] = (bok[f] && in0) ? q[0] : zero4;
-      bv[f][1] = (bok[f] && in1) ? q[4] : zero4;
+      const int r = j0 + 16 * f + li_;
+      const bool ok = r < p.mb;
+      const u32x4* q = reinterpret_cast<const u32x4*>(B + ((unsigned)(ok ? r : 0) * un + px));
+      bv[f][0] = (ok && in0) ? q[0] : zero4;
+      bv[f][1] = (ok && in1) ? q[4] : zero4;
     }
   };
 

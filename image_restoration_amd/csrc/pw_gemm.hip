@@ -764,7 +764,8 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
   bf16* const Wl = reinterpret_cast<bf16*>(lds_dyn);                 // [m_tiles][KB][64][WS_ROW]
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: the wave's patch, tile range and their addresses stay out of the VGPRs
   bf16* const patch = Wl + (int64_t)m_tiles * KB * TM * WS_ROW + wv * PWW_PATCH;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
@@ -798,20 +799,23 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
     const int64_t tile = tile0 + tt;
     if (tile >= n_tiles) break;
     const int64_t n0 = tile * PW_TN;
+    int ln = lane;                                                   // opaque copy of the lane id: see pw_gemm_wave_stream_kernel
+    asm volatile("" : "+v"(ln));
+    const int li_ = ln & 15, g_ = ln >> 4;
     if (q.ln_mode)
       pww_ln_inplace<KB>(raw, x.ktot, lnp, q.ln_mode, q.ln_mean ? q.ln_mean + zb * p.n + n0 : nullptr,
-                         q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, lane);
+                         q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, ln);
     s16x8 a[KB][4];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) pww_chunk_to_frags(a[kb], raw[kb], patch, kb, x.ktot, lane);
+    for (int kb = 0; kb < KB; ++kb) pww_chunk_to_frags(a[kb], raw[kb], patch, kb, x.ktot, ln);
     if (tt + 1 < tiles_per_wave && tile + 1 < n_tiles) {             // the next tile's X flies while this tile's channels are computed
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) pww_load_chunk(raw[kb], x, kb, n0 + PW_TN, lane);
+      for (int kb = 0; kb < KB; ++kb) pww_load_chunk(raw[kb], x, kb, n0 + PW_TN, ln);
     }
     for (int mh = 0; mh < 2 * m_tiles; ++mh) {                       // 32 output channels per trip
       const int mbase = 32 * mh;
       if (mbase >= p.m) break;
-      const bf16* wt = Wl + (int64_t)(mh >> 1) * KB * TM * WS_ROW + ((mh & 1) * 32 + li) * WS_ROW + 4 * g;
+      const bf16* wt = Wl + (int64_t)(mh >> 1) * KB * TM * WS_ROW + ((mh & 1) * 32 + li_) * WS_ROW + 4 * g_;
       f32x4 acc[2][4];
 #pragma unroll
       for (int f = 0; f < 2; ++f)
@@ -826,13 +830,13 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
           for (int nf = 0; nf < 4; ++nf) acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][nf], b, acc[f][nf], 0, 0, 0);
         }
       if (!o.r) {
-        pww_store_bf16<2>(acc[0], acc[1], patch, o, mbase, n0, lane);
+        pww_store_bf16<2>(acc[0], acc[1], patch, o, mbase, n0, ln);
       } else {                                                       // (no model shape takes this branch: wide outputs carry no residual)
         u32x4 rr[2];
-        pww_load_res(rr, o, mbase, n0, lane);
-        pww_store_frag(acc[0], rr, reinterpret_cast<float*>(patch), o, mbase, n0, lane);
-        pww_load_res(rr, o, mbase + 16, n0, lane);
-        pww_store_frag(acc[1], rr, reinterpret_cast<float*>(patch), o, mbase + 16, n0, lane);
+        pww_load_res(rr, o, mbase, n0, ln);
+        pww_store_frag(acc[0], rr, reinterpret_cast<float*>(patch), o, mbase, n0, ln);
+        pww_load_res(rr, o, mbase + 16, n0, ln);
+        pww_store_frag(acc[1], rr, reinterpret_cast<float*>(patch), o, mbase + 16, n0, ln);
       }
     }
   }
@@ -845,7 +849,8 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
   bf16* const Wl = reinterpret_cast<bf16*>(lds_dyn);                 // [k_chunks][TM][WS_ROW]
   const int nchunks = q.k_chunks;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, g = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: the wave's patch, tile range and their addresses stay out of the VGPRs
   bf16* const patch = Wl + (int64_t)nchunks * TM * WS_ROW + wv * PWW_PATCH;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
@@ -869,19 +874,21 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
     const int64_t tile = tile0 + tt;
     if (tile >= n_tiles) break;
     const int64_t n0 = tile * PW_TN;
+    int ln = lane;                                                   // opaque copy: the per-lane address terms below are loop-invariant,
+    asm volatile("" : "+v"(ln));                                     // and hoisted out of the tile loop they cost registers this kernel lacks
     f32x4 acc[MF][4];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     u32x4 r0[4], r1[4];                                              // two chunks in flight, statically named
-    pww_load_chunk(r0, x, 0, n0, lane);
-    if (nchunks > 1) pww_load_chunk(r1, x, 1, n0, lane);
+    pww_load_chunk(r0, x, 0, n0, ln);
+    if (nchunks > 1) pww_load_chunk(r1, x, 1, n0, ln);
     for (int kb = 0; kb < nchunks; kb += 2) {
       {
         s16x8 a[4];
-        pww_chunk_to_frags(a, r0, patch, kb, x.ktot, lane);
-        if (kb + 2 < nchunks) pww_load_chunk(r0, x, kb + 2, n0, lane);
+        pww_chunk_to_frags(a, r0, patch, kb, x.ktot, ln);
+        if (kb + 2 < nchunks) pww_load_chunk(r0, x, kb + 2, n0, ln);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
           const s16x8 b = pww_w_frag(wl + (kb * TM + 16 * mf) * WS_ROW);
@@ -891,8 +898,8 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
       }
       if (kb + 1 < nchunks) {
         s16x8 a[4];
-        pww_chunk_to_frags(a, r1, patch, kb + 1, x.ktot, lane);
-        if (kb + 3 < nchunks) pww_load_chunk(r1, x, kb + 3, n0, lane);
+        pww_chunk_to_frags(a, r1, patch, kb + 1, x.ktot, ln);
+        if (kb + 3 < nchunks) pww_load_chunk(r1, x, kb + 3, n0, ln);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
           const s16x8 b = pww_w_frag(wl + ((kb + 1) * TM + 16 * mf) * WS_ROW);
@@ -904,17 +911,17 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
     if (!o.r) {
 #pragma unroll
       for (int mj = 0; mj < MF / 2; ++mj)
-        if (m0 + 32 * mj < p.m) pww_store_bf16<2>(acc[2 * mj], acc[2 * mj + 1], patch, o, m0 + 32 * mj, n0, lane);
+        if (m0 + 32 * mj < p.m) pww_store_bf16<2>(acc[2 * mj], acc[2 * mj + 1], patch, o, m0 + 32 * mj, n0, ln);
       if (MF & 1)
-        if (m0 + 16 * (MF - 1) < p.m) pww_store_bf16<1>(acc[MF - 1], acc[MF - 1], patch, o, m0 + 16 * (MF - 1), n0, lane);
+        if (m0 + 16 * (MF - 1) < p.m) pww_store_bf16<1>(acc[MF - 1], acc[MF - 1], patch, o, m0 + 16 * (MF - 1), n0, ln);
     } else {
       u32x4 rr[2], rn[2];                                            // residual rows: one fragment ahead
-      pww_load_res(rr, o, m0, n0, lane);
+      pww_load_res(rr, o, m0, n0, ln);
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         if (m0 + 16 * mf >= p.m) break;
-        if (mf + 1 < MF) pww_load_res(rn, o, m0 + 16 * (mf + 1), n0, lane);
-        pww_store_frag(acc[mf], rr, reinterpret_cast<float*>(patch), o, m0 + 16 * mf, n0, lane);
+        if (mf + 1 < MF) pww_load_res(rn, o, m0 + 16 * (mf + 1), n0, ln);
+        pww_store_frag(acc[mf], rr, reinterpret_cast<float*>(patch), o, m0 + 16 * mf, n0, ln);
         rr[0] = rn[0]; rr[1] = rn[1];
       }
     }
