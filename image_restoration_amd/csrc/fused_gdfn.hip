@@ -338,7 +338,13 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
 #pragma unroll
       for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const int lane_outer = lane;
   for (int c = 0; c < a.nch; ++c) {
+    // Lane coordinates of the chunk loop come from an opaque copy of the lane id (they shadow the outer ones): the per-lane LDS
+    // addresses of the three phases are loop-invariant, and hoisted out of this loop they are what the kernel spills.
+    int lane_o = lane_outer;
+    asm volatile("" : "+v"(lane_o));
+    const int lane = lane_o, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3, t = wv * 64 + lane;
     // ------------------------------------------------------------ GEMM1: h0 chunk = W_in'[chunk] . LN(y), to LDS
     if (!(a.dbg & 32)) {
 #pragma unroll
