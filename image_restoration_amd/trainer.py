@@ -25,7 +25,10 @@ ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the fla
 class FlatTrainer:
     def __init__(self, model: nn.Module, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, process_group=None, overlap: bool = True, host_update=None,
-                 pack_cache: bool = True, bucket_blocks: bool = True):
+                 pack_cache: bool = True, bucket_blocks: bool = True, shard_optimizer: bool = False):
+        """shard_optimizer: reduce-scatter the flat gradient, run AdamW on this rank's 1/world slice of the parameters (the two
+        moment buffers shrink to that slice), all-gather the updated parameters - instead of all-reduce + replicated AdamW.
+        One collective pair per step after backward (no per-stage overlap); for models whose optimizer state matters."""
         self.model = model
         # host_update(trainer, scale): test hook that stands in for the fused AdamW kernel when the gradient-bucketing /
         # all-reduce bookkeeping is exercised on CPU tensors over gloo.  The product has no CPU update: without the hook,
@@ -44,10 +47,18 @@ class FlatTrainer:
         for p in params:
             offs.append(total)
             total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.sharded = bool(shard_optimizer) and self.world > 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        if self.sharded:                                   # equal, aligned shards: pad the flat buffers at the end
+            self.shard = (total + self.world * ALIGN - 1) // (self.world * ALIGN) * ALIGN
+            total = self.shard * self.world
+        else:
+            self.shard = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p)
-        self.flat_m = torch.zeros_like(self.flat_p)
-        self.flat_v = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros_like(self.flat_m)
+        self._g_shard = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.sharded else None
         self.offsets: Dict[int, Tuple[int, int]] = {}
         with torch.no_grad():
             for p, o in zip(params, offs):
@@ -75,7 +86,7 @@ class FlatTrainer:
                 hi = max(self.offsets[id(p)][0] + (self.offsets[id(p)][1] + ALIGN - 1) // ALIGN * ALIGN for p in ps)
                 self.stages.append((uname, unit, lo, hi))
         self._param_lists: dict = {}
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.world > 1 and not self.sharded
         self._exec_order: List[int] = []
         self._reduced: set = set()
         self._works = []
@@ -131,11 +142,15 @@ class FlatTrainer:
     # state_dict carries the parameters: Lightning's checkpoint holds both, MoCE-IR-main/src/train.py:107-116,137-148)
     def state_dict(self) -> dict:
         return {"exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone(), "step": self.step_count, "lr": self.lr,
-                "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "numel": int(self.total)}
+                "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "numel": int(self.total),
+                "shard": (self.rank, self.world) if self.sharded else None}
 
     def load_state_dict(self, sd: dict) -> None:
         if int(sd["numel"]) != int(self.total):
             raise ValueError(f"optimizer state is for {sd['numel']} flat elements, this trainer has {self.total}")
+        want = (self.rank, self.world) if self.sharded else None
+        if sd.get("shard") != want:
+            raise ValueError(f"optimizer state was saved for shard {sd.get('shard')}, this trainer is {want}")
         self.flat_m.copy_(sd["exp_avg"])
         self.flat_v.copy_(sd["exp_avg_sq"])
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
@@ -237,6 +252,15 @@ class FlatTrainer:
         if self.world == 1:
             self._fold_autograd_grads(self.model)
             return
+        if self.sharded:
+            self._fold_autograd_grads(self.model)
+            lo = self.rank * self.shard
+            if dist.get_backend(self.pg) == "gloo":        # gloo has no reduce-scatter: same result by all-reduce + slice
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+                self._g_shard.copy_(self.flat_g[lo:lo + self.shard])
+            else:
+                dist.reduce_scatter_tensor(self._g_shard, self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            return
         for idx in range(len(self.stages) - 1, -1, -1):
             self._mark_ready(idx)
         for w in self._works:
@@ -256,6 +280,30 @@ class FlatTrainer:
     def optimizer_step(self, use_dev_scalars: bool = False) -> None:
         self.step_count += 1
         scale = 1.0 / self.world
+        if self.sharded:
+            lo = self.rank * self.shard
+            p_shard = self.flat_p[lo:lo + self.shard]
+            if self.flat_p.is_cuda:
+                ops.adamw_step(p_shard, self._g_shard, self.flat_m, self.flat_v, self.lr, self.step_count, self.betas, self.eps,
+                               self.wd, scale, self.dev_scalars if use_dev_scalars else None)
+            elif self._host_update is not None:
+                import types
+                self._host_update(types.SimpleNamespace(flat_p=p_shard, flat_g=self._g_shard, flat_m=self.flat_m,
+                                                        flat_v=self.flat_v, betas=self.betas, lr=self.lr, wd=self.wd,
+                                                        eps=self.eps, step_count=self.step_count), scale)
+            else:
+                raise RuntimeError("FlatTrainer.optimizer_step: parameters are not on an MI355X (no CPU optimizer path)")
+            if dist.get_backend(self.pg) == "gloo":
+                parts = [torch.empty_like(p_shard) for _ in range(self.world)]
+                dist.all_gather(parts, p_shard.clone(), group=self.pg)
+                for r, part in enumerate(parts):
+                    self.flat_p[r * self.shard:(r + 1) * self.shard].copy_(part)
+            else:
+                dist.all_gather_into_tensor(self.flat_p, p_shard, group=self.pg)     # in place: each rank's slice is its input
+            if self._pack_cache and self.flat_p.is_cuda:
+                ops.pw_cache_refresh()
+                self._p_version = self.flat_p._version
+            return
         if self.flat_p.is_cuda:
             ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.step_count, self.betas,
                            self.eps, self.wd, scale, self.dev_scalars if use_dev_scalars else None)

@@ -58,7 +58,13 @@ def _worker(rank, world, port, overlap, ret):
         from image_restoration_amd.trainer import FlatTrainer
         torch.manual_seed(0)
         model = TinyNet()
-        tr = FlatTrainer(model, lr=1e-2, overlap=overlap, host_update=_host_adamw)
+        sharded = overlap == "sharded"
+        tr = FlatTrainer(model, lr=1e-2, overlap=bool(overlap) and not sharded, host_update=_host_adamw, shard_optimizer=sharded)
+        if sharded:     # moments cover this rank's slice only; the flat buffers are padded to world equal shards
+            assert tr.flat_m.numel() == tr.shard and tr.flat_p.numel() == tr.shard * world and not tr.overlap
+            sd = tr.state_dict()
+            assert sd["shard"] == (rank, world)
+            tr.load_state_dict(sd)
         # embed, enc.0, enc.2, dec.0, out: nn.Sequential stages are bucketed per block
         assert tr.world == world and [n for n, *_ in tr.stages] == ["embed", "enc.0", "enc.2", "dec.0", "out"]
         g = torch.Generator().manual_seed(1)
@@ -78,8 +84,10 @@ def _worker(rank, world, port, overlap, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "sharded"])
 def test_two_rank_training_matches_single_process(overlap):
+    """overlap True / False: all-reduce from the backward hooks / after backward; "sharded": reduce-scatter, AdamW on each rank's
+    slice of the flat parameters, all-gather (FlatTrainer(shard_optimizer=True))."""
     torch.manual_seed(0)
     ref = TinyNet()
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
