@@ -71,7 +71,8 @@ def gdfn(x: Tensor, w_in: Tensor, w_dw: Tensor, w_out: Tensor,
 # --------------------------------------------------------------------------
 def _l2_normalize_rows(t: Tensor) -> Tensor:
     # F.normalize(dim=-1): x / max(||x||_2, eps)   (Restormer.py:121-122)
-    n = t.pow(2).sum(dim=-1, keepdim=True).sqrt().clamp_min(NORMALIZE_EPS)
+    # (Tensor.norm, not sum-of-squares + sqrt: its backward is 0 at an all-zero row - AdaIR's empty low band - where sqrt'(0) = inf)
+    n = t.norm(p=2, dim=-1, keepdim=True).clamp_min(NORMALIZE_EPS)
     return t / n
 
 
