@@ -135,6 +135,23 @@ SIGNATURES = {
     "mi_mdta_fwd_ln": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
     "mi_gdfn_fwd_ln_ok": (C.c_int, [C.POINTER(GdfnShape)]),
     "mi_gdfn_fwd_ln": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
+    "mi_box_down": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_fre_rect": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_fre_split_coef_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mi_fre_split_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_fre_split_max_hw": (C.c_int, []),
+    "mi_fre_split_fwd": (C.c_int, [vp, vp, vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_fre_split_bwd": (C.c_int, [vp, vp, fp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mi_chan_maxmean_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_chan_maxmean_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_plane_max_fwd": (C.c_int, [vp, fp, vp, C.c_int, c_i64, C.c_int, vp]),
+    "mi_pool_pair_bwd": (C.c_int, [fp, fp, vp, vp, C.c_int, c_i64, C.c_int, vp]),
+    "mi_chan_gate_fwd": (C.c_int, [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_chan_gate_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_refine_mix_fwd": (C.c_int, [vp, vp, vp, fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_refine_mix_bwd": (C.c_int, [vp, vp, vp, fp, vp, vp, vp, vp, fp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_scale_add_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, c_i64, C.c_int, vp]),
+    "mi_scale_add_bwd": (C.c_int, [vp, vp, fp, fp, vp, vp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "mi_bwd_tail_ok": (C.c_int, [C.c_int, C.c_int, c_i64, C.c_int]),
     "mi_bwd_tail_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "mi_bwd_tail": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, fp, fp, fp, fp, fp, vp, fp, fp, fp, C.c_int, c_i64, C.c_int,

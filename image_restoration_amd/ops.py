@@ -788,3 +788,133 @@ def prof_collect():
         if cnt[i]:
             out[lib.mi_prof_kernel_name(i).decode()] = dict(ms=ms[i], bytes=by[i], flops=fl[i], launches=int(cnt[i]))
     return out
+
+
+# ----------------------------------------------------------------------------- AdaIR frequency modules (csrc/adair.hip)
+def box_down(img: Tensor, H: int, W: int) -> Tensor:
+    """F.interpolate(img, (H, W), mode='bilinear') for the integer level factors (1, 2, 4, 8 ...)."""
+    _gpu(img)
+    B, Cc, Hi, Wi = img.shape
+    if Hi % H or Wi % W or Hi // H != Wi // W:
+        raise ValueError(f"box_down: {Hi}x{Wi} -> {H}x{W} is not an integer level factor")
+    out = torch.empty((B, Cc, H, W), dtype=img.dtype, device=img.device)
+    L.check(L.lib().mi_box_down(_p(img), _p(out), B, Cc, Hi, Wi, Hi // H, _dt(img), _stream()), "box_down")
+    return out
+
+
+def fre_rect(pooled: Tensor, w0: Tensor, w2: Tensor, H: int, W: int, n: int = 128) -> Tensor:
+    _gpu(pooled, w0, w2)
+    B, Cc = pooled.shape
+    half = torch.empty((B, 2), dtype=torch.int32, device=pooled.device)
+    L.check(L.lib().mi_fre_rect(_p(pooled), _p(w0), _p(w2), _p(half), B, Cc, w0.shape[0], H, W, n, _stream()), "fre_rect")
+    return half
+
+
+def fre_split_fwd(feat: Tensor, half: Optional[Tensor]):
+    _gpu(feat, half)
+    B, Cc, H, W = feat.shape
+    high, low = torch.empty_like(feat), torch.empty_like(feat)
+    coef = None
+    if half is not None:
+        coef = torch.empty(L.lib().mi_fre_split_coef_bytes(B, Cc) // 4, dtype=torch.float32, device=feat.device)
+    L.check(L.lib().mi_fre_split_fwd(_p(feat), _p(half), _p(high), _p(low), _p(coef), B, Cc, H, W, _dt(feat), _stream()),
+            "fre_split_fwd")
+    return high, low, coef
+
+
+def fre_split_bwd(feat: Tensor, half: Optional[Tensor], coef: Optional[Tensor], dhigh: Tensor, dlow: Tensor) -> Tensor:
+    _gpu(feat, half, coef, dhigh, dlow)
+    B, Cc, H, W = feat.shape
+    dfeat = torch.empty_like(feat)
+    ws = _ws(L.lib().mi_fre_split_workspace(B, Cc, H, W), feat.device)
+    L.check(L.lib().mi_fre_split_bwd(_p(feat), _p(half), _p(coef), _p(dhigh), _p(dlow), _p(dfeat), B, Cc, H, W, _dt(feat),
+                                     _p(ws), _stream()), "fre_split_bwd")
+    return dfeat
+
+
+def chan_maxmean_fwd(x: Tensor):
+    _gpu(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, 2, H, W), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, H * W), dtype=torch.int32, device=x.device)
+    L.check(L.lib().mi_chan_maxmean_fwd(_p(x), _p(out), _p(idx), B, Cc, H * W, _dt(x), _stream()), "chan_maxmean_fwd")
+    return out, idx
+
+
+def chan_maxmean_bwd(dout: Tensor, idx: Tensor, Cc: int) -> Tensor:
+    _gpu(dout, idx)
+    B, _, H, W = dout.shape
+    dx = torch.empty((B, Cc, H, W), dtype=dout.dtype, device=dout.device)
+    L.check(L.lib().mi_chan_maxmean_bwd(_p(dout), _p(idx), _p(dx), B, Cc, H * W, _dt(dout), _stream()), "chan_maxmean_bwd")
+    return dx
+
+
+def plane_max_fwd(x: Tensor):
+    _gpu(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, Cc), dtype=torch.int32, device=x.device)
+    L.check(L.lib().mi_plane_max_fwd(_p(x), _p(out), _p(idx), B * Cc, H * W, _dt(x), _stream()), "plane_max_fwd")
+    return out, idx
+
+
+def pool_pair_bwd(davg: Tensor, dmax: Tensor, idx: Tensor, like: Tensor) -> Tensor:
+    _gpu(davg, dmax, idx)
+    B, Cc, H, W = like.shape
+    dx = torch.empty_like(like)
+    L.check(L.lib().mi_pool_pair_bwd(_p(davg), _p(dmax), _p(idx), _p(dx), B * Cc, H * W, _dt(like), _stream()), "pool_pair_bwd")
+    return dx
+
+
+def chan_gate_fwd(avg: Tensor, mx: Tensor, w1: Tensor, w2: Tensor):
+    _gpu(avg, mx, w1, w2)
+    B, Cc = avg.shape
+    R_ = w1.shape[0]
+    cw = torch.empty_like(avg)
+    hid = torch.empty((B, 2, R_), dtype=torch.float32, device=avg.device)
+    L.check(L.lib().mi_chan_gate_fwd(_p(avg), _p(mx), _p(w1), _p(w2), _p(cw), _p(hid), B, Cc, R_, _stream()), "chan_gate_fwd")
+    return cw, hid
+
+
+def chan_gate_bwd(avg, mx, w1, w2, cw, hid, dcw, dw1, dw2, accumulate: bool):
+    _gpu(avg, mx, w1, w2, cw, hid, dcw, dw1, dw2)
+    B, Cc = avg.shape
+    davg, dmx = torch.empty_like(avg), torch.empty_like(avg)
+    L.check(L.lib().mi_chan_gate_bwd(_p(avg), _p(mx), _p(w1), _p(w2), _p(cw), _p(hid), _p(dcw), _p(davg), _p(dmx), _p(dw1), _p(dw2),
+                                     B, Cc, w1.shape[0], int(accumulate), _stream()), "chan_gate_bwd")
+    return davg, dmx
+
+
+def refine_mix_fwd(low: Tensor, high: Tensor, s: Tensor, cw: Tensor) -> Tensor:
+    _gpu(low, high, s, cw)
+    B, Cc, H, W = low.shape
+    out = torch.empty_like(low)
+    L.check(L.lib().mi_refine_mix_fwd(_p(low), _p(high), _p(s), _p(cw), _p(out), B, Cc, H * W, _dt(low), _stream()), "refine_mix_fwd")
+    return out
+
+
+def refine_mix_bwd(low: Tensor, high: Tensor, s: Tensor, cw: Tensor, dout: Tensor):
+    _gpu(low, high, s, cw, dout)
+    B, Cc, H, W = low.shape
+    dlow, dhigh, ds = torch.empty_like(low), torch.empty_like(low), torch.empty_like(s)
+    dcw = torch.empty_like(cw)
+    L.check(L.lib().mi_refine_mix_bwd(_p(low), _p(high), _p(s), _p(cw), _p(dout), _p(dlow), _p(dhigh), _p(ds), _p(dcw), B, Cc, H * W,
+                                      _dt(low), _stream()), "refine_mix_bwd")
+    return dlow, dhigh, ds, dcw
+
+
+def scale_add_fwd(a: Tensor, y: Tensor, p1: Tensor, p2: Tensor) -> Tensor:
+    _gpu(a, y, p1, p2)
+    B, Cc, H, W = a.shape
+    out = torch.empty_like(a)
+    L.check(L.lib().mi_scale_add_fwd(_p(a), _p(y), _p(p1), _p(p2), _p(out), B, Cc, H * W, _dt(a), _stream()), "scale_add_fwd")
+    return out
+
+
+def scale_add_bwd(a: Tensor, y: Tensor, p1: Tensor, p2: Tensor, dout: Tensor, dp1: Tensor, dp2: Tensor, accumulate: bool):
+    _gpu(a, y, p1, p2, dout, dp1, dp2)
+    B, Cc, H, W = a.shape
+    da, dy = torch.empty_like(a), torch.empty_like(a)
+    L.check(L.lib().mi_scale_add_bwd(_p(a), _p(y), _p(p1), _p(p2), _p(dout), _p(da), _p(dy), _p(dp1), _p(dp2), B, Cc, H * W,
+                                     int(accumulate), _dt(a), _stream()), "scale_add_bwd")
+    return da, dy

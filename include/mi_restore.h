@@ -291,6 +291,48 @@ int mi_gdfn_bwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_
                    void* dx, const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * AdaIR frequency modules (AdaIR-main/net/model.py:230-372): the pieces of SpatialGate / ChannelGate / FreRefine / FreModule
+ * that are not a block, a cross attention or a convolution (csrc/adair.hip).  Activations [B,C,H,W] in `dtype`, N = H*W.
+ *   mi_box_down          F.interpolate(img, (H, W), 'bilinear') for the integer factors of the U-Net levels (model.py:321)
+ *   mi_fre_rect          half sizes [B,2] of the low-frequency rectangle: int(h/n * sigmoid(rate_conv(avgpool))) (model.py:346-353)
+ *   mi_fre_split_fwd/bwd FreModule.fft (model.py:343-372): high = |x - Px|, low = |Px|, P = the projection on the rectangle's
+ *                        frequencies evaluated as a direct DFT (no FFT); half == NULL: empty rectangle for every sample.
+ *                        coef: mi_fre_split_coef_bytes (kept for the backward); ws: mi_fre_split_workspace.
+ *   mi_chan_maxmean_*    [max_c x, mean_c x] -> [B,2,H,W] + arg max [B,N] (model.py:240-242)
+ *   mi_plane_max_fwd     global max pool + arg max per plane; mi_pool_pair_bwd: gradient of avg pool + max pool in one pass (model.py:250-264)
+ *   mi_chan_gate_*       sigmoid(mlp(avg) + mlp(max)), mlp = W2 relu(W1 .) (model.py:253-268); hid [B,2,R] pre-activations
+ *   mi_refine_mix_*      low * sigmoid(s0 + s1) + high * cw (model.py:284-288), s [B,2,H,W] = depthwise 7x7 of the max/mean planes
+ *   mi_scale_add_*       a * p1[c] + y * p2[c] (model.py:331) and the parameter gradients
+ * ------------------------------------------------------------------------ */
+int mi_box_down(const void* img, void* out, int B, int C, int Hi, int Wi, int factor, int dtype, void* stream);
+int mi_fre_rect(const float* pooled, const float* w0, const float* w2, int* half, int B, int C, int R, int H, int W, int n,
+                void* stream);
+size_t mi_fre_split_coef_bytes(int B, int C);
+size_t mi_fre_split_workspace(int B, int C, int H, int W);
+int mi_fre_split_max_hw(void);
+int mi_fre_split_fwd(const void* feat, const int* half, void* high, void* low, float* coef, int B, int C, int H, int W, int dtype,
+                     void* stream);
+int mi_fre_split_bwd(const void* feat, const int* half, const float* coef, const void* dhigh, const void* dlow, void* dfeat, int B,
+                     int C, int H, int W, int dtype, void* ws, void* stream);
+int mi_chan_maxmean_fwd(const void* x, void* out, int* idx, int B, int C, int64_t N, int dtype, void* stream);
+int mi_chan_maxmean_bwd(const void* dout, const int* idx, void* dx, int B, int C, int64_t N, int dtype, void* stream);
+int mi_plane_max_fwd(const void* x, float* out, int* idx, int planes, int64_t N, int dtype, void* stream);
+int mi_pool_pair_bwd(const float* davg, const float* dmax, const int* idx, void* dx, int planes, int64_t N, int dtype, void* stream);
+int mi_chan_gate_fwd(const float* avg, const float* mx, const float* w1, const float* w2, float* cw, float* hid, int B, int C, int R,
+                     void* stream);
+int mi_chan_gate_bwd(const float* avg, const float* mx, const float* w1, const float* w2, const float* cw, const float* hid,
+                     const float* dcw, float* davg, float* dmx, float* dw1, float* dw2, int B, int C, int R, int accumulate,
+                     void* stream);
+int mi_refine_mix_fwd(const void* low, const void* high, const void* s, const float* cw, void* out, int B, int C, int64_t N,
+                      int dtype, void* stream);
+int mi_refine_mix_bwd(const void* low, const void* high, const void* s, const float* cw, const void* dout, void* dlow, void* dhigh,
+                      void* ds, float* dcw, int B, int C, int64_t N, int dtype, void* stream);
+int mi_scale_add_fwd(const void* a, const void* y, const float* p1, const float* p2, void* out, int B, int C, int64_t N, int dtype,
+                     void* stream);
+int mi_scale_add_bwd(const void* a, const void* y, const float* p1, const float* p2, const void* dout, void* da, void* dy, float* dp1,
+                     float* dp2, int B, int C, int64_t N, int accumulate, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * Training-step tail on flat fp32 buffers (MoCE-IR-main/src/train.py:79-88:
  * AdamW(lr=2e-4), torch defaults betas (0.9,0.999), eps 1e-8, weight_decay 1e-2).
  * p, g, m, v: [n] fp32.  grad_scale multiplies g first (1/world for DDP mean).
