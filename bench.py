@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", choices=["restormer", "moce"], default="restormer")
+    ap.add_argument("--model", choices=["restormer", "moce", "adair"], default="restormer")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 Restormer / 8 MoCE-IR; 8 = BASELINE configs[1])")
     ap.add_argument("--patch", type=int, default=0, help="patch size (default 256 Restormer / 128 MoCE-IR)")
@@ -193,6 +193,9 @@ def main():
         if moce:
             from image_restoration_amd.moce_ir import MoCEIR
             return MoCEIR(**configs.MOCEIR_BASE).to(dev).train()
+        if args.model == "adair":
+            from image_restoration_amd.adair import AdaIR
+            return AdaIR(**configs.ADAIR_BASE).to(dev).train()
         return m.Restormer(**configs.RESTORMER_BASE).to(dev)
 
     model = build_model()
@@ -206,7 +209,7 @@ def main():
     clean = clean32.to(dev).to(act)
     noisy = noisy32.to(dev).to(act)
 
-    use_graph = args.graph == 1 and world == 1 and not moce
+    use_graph = args.graph == 1 and world == 1 and args.model == "restormer"
     step, loss_buf = make_step(model, trainer, noisy, clean, use_dev_scalars=use_graph, moce=moce)
 
     def run_eager(n):
@@ -364,6 +367,10 @@ def main():
             workload = (f"MoCE-IR (dim 48, enc [4,6,6,8], dec [2,4,4], 4 experts top-1, {n_params / 1e6:.2f}M params) train step: "
                         f"fwd + L1 + 0.01 balance loss + bwd + AdamW, {patch}x{patch} patches, bs {batch}/GPU, {args.dtype} "
                         f"activations, fp32 params/grads/optimizer")
+        elif args.model == "adair":
+            metric = f"Mpixels/sec train (AdaIR base {patch}x{patch}, bs {batch}/GPU)"
+            workload = (f"AdaIR (Restormer base U-Net + 3 FreModules, {n_params / 1e6:.2f}M params) train step: fwd + L1 + bwd + "
+                        f"AdamW, {patch}x{patch} patches, bs {batch}/GPU, {args.dtype} activations, fp32 params/grads/optimizer")
         else:
             metric = ("Mpixels/sec train (Restormer base 256x256, bs 32/GPU)" if (batch == 32 and patch == 256) else
                       f"Mpixels/sec train (Restormer base {patch}x{patch}, bs {batch}/GPU)")

@@ -14,6 +14,9 @@ MOCEIR_BASE = dict(dim=48, num_blocks=[4, 6, 6, 8], num_dec_blocks=[2, 4, 4], le
                    num_refinement_blocks=4, topk=1, num_experts=4, rank=2, with_complexity=False, depth_type="constant",
                    stage_depth=[1, 1, 1], rank_type="spread", complexity_scale="max")
 MOCEIR_S = dict(MOCEIR_BASE, dim=32)
+# AdaIR-main/net/model.py:380-390 constructor defaults (the Restormer U-Net + three FreModules; AdaIR-main/train.py builds it bare)
+ADAIR_BASE = dict(dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66,
+                  bias=False, LayerNorm_type="WithBias", decoder=True)
 
 # analytic work of one Restormer-base forward at 256 x 256: used by bench.py's whole-step roofline
 RESTORMER_BASE_FWD_FLOP_PER_PIXEL = 4.80e6          # 314.5 GFLOP per 256^2 image; a training step is ~3x
