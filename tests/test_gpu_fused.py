@@ -202,6 +202,30 @@ def test_bwd_tail_vs_fp64(c, mrows, shape, accumulate):
     assert rel(dbeta - off, rdb) < 1e-2, rel(dbeta - off, rdb)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_bwd_tail_random_shapes(seed):
+    """Random covered shapes (rows not a multiple of 16, odd tile counts, 1-5 images) against the fp64 statement."""
+    import numpy as np
+    from image_restoration_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    c = int(rng.choice([48, 96]))
+    mrows = int(rng.integers(17, 256 if c == 48 else 512))
+    B, tiles = int(rng.integers(1, 6)), int(rng.integers(1, 40))
+    H, W = 8, 8 * tiles                                          # H*W = 64 * tiles
+    assert ops.bwd_tail_ok(mrows, c, H * W, torch.bfloat16)
+    x = (seeded_input((B, c, H, W), 2000 + seed) * 2.0 - 0.5).to(DEV).to(torch.bfloat16)
+    dy = seeded_input((B, mrows, H, W), 2100 + seed).to(DEV).to(torch.bfloat16)
+    dres = seeded_input((B, c, H, W), 2200 + seed).to(DEV).to(torch.bfloat16)
+    w = (seeded_input((mrows, c), 2300 + seed) * 0.3).to(DEV).float().contiguous()
+    gamma = (1.0 + 0.3 * seeded_input((c,), 2400 + seed)).to(DEV).float()
+    beta = (0.2 * seeded_input((c,), 2500 + seed)).to(DEV).float()
+    _, mean, rstd = ops.ln_fwd(x, gamma, beta, True, want_stats=True)
+    dw, dgamma, dbeta = (torch.full(s_, float("nan"), device=DEV) for s_ in ((mrows, c), (c,), (c,)))
+    dx = ops.bwd_tail(dy, x, dres, mean, rstd, w, gamma, beta, dw, dgamma, dbeta, False)
+    rdx, rdw, rdg, rdb = _tail_reference(dy, x, dres, w, gamma, beta)
+    assert rel(dx, rdx) < 2e-2 and rel(dw, rdw) < 1e-2 and rel(dgamma, rdg) < 1e-2 and rel(dbeta, rdb) < 1e-2, (c, mrows, B, tiles)
+
+
 def test_bwd_tail_rejects_uncovered_shapes():
     from image_restoration_amd import ops
     assert not ops.bwd_tail_ok(576, 192, 4096, torch.bfloat16)       # C = 192: unfused chain

