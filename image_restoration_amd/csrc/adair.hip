@@ -445,6 +445,7 @@ extern "C" int mi_box_down(const void* img, void* out, int B, int C, int Hi, int
                "box_down: the level must be an even integer factor below the image (got %d for %d x %d)", factor, Hi, Wi);
   const int64_t total = (int64_t)B * C * (Hi / factor) * (Wi / factor);
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   int blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
   AD_DISPATCH(dtype, hipLaunchKernelGGL((box_down_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)img, (float*)out, Hi, Wi, factor, total),
@@ -474,6 +475,7 @@ extern "C" int mi_fre_split_fwd(const void* feat, const int* half, void* high, v
   MI_CHECK_ARG(feat && high && low && B > 0 && C > 0 && H > 0 && W > 0, "fre_split_fwd: bad arguments");
   MI_CHECK_ARG(!half || coef, "fre_split_fwd: a rectangle needs the coefficient buffer");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   const int64_t N = (int64_t)H * W;
   dim3 grid(cdiv(N, 256), B * C);
   MI_CHECK_ARG(grid.y <= 65535, "fre_split_fwd: too many planes");
@@ -493,6 +495,7 @@ extern "C" int mi_fre_split_bwd(const void* feat, const int* half, const float* 
   MI_CHECK_ARG(feat && dhigh && dlow && dfeat && ws && B > 0 && C > 0, "fre_split_bwd: bad arguments");
   MI_CHECK_ARG(!half || coef, "fre_split_bwd: a rectangle needs the forward's coefficients");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   const int64_t N = (int64_t)H * W;
   dim3 grid(cdiv(N, 256), B * C);
   Carver cv(ws);
@@ -516,6 +519,7 @@ extern "C" int mi_fre_split_bwd(const void* feat, const int* half, const float* 
 extern "C" int mi_chan_maxmean_fwd(const void* x, void* out, int* idx, int B, int C, int64_t N, int dtype, void* stream) {
   MI_CHECK_ARG(x && out && idx && B > 0 && C > 0 && N > 0, "chan_maxmean_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((chan_maxmean_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (float*)out, idx, C, N),
               hipLaunchKernelGGL((chan_maxmean_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)out, idx, C, N));
@@ -525,6 +529,7 @@ extern "C" int mi_chan_maxmean_fwd(const void* x, void* out, int* idx, int B, in
 extern "C" int mi_chan_maxmean_bwd(const void* dout, const int* idx, void* dx, int B, int C, int64_t N, int dtype, void* stream) {
   MI_CHECK_ARG(dout && idx && dx && B > 0 && C > 0 && N > 0, "chan_maxmean_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((chan_maxmean_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, idx, (float*)dx, C, N),
               hipLaunchKernelGGL((chan_maxmean_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, C, N));
@@ -535,6 +540,7 @@ extern "C" int mi_chan_maxmean_bwd(const void* dout, const int* idx, void* dx, i
 extern "C" int mi_plane_max_fwd(const void* x, float* out, int* idx, int planes, int64_t N, int dtype, void* stream) {
   MI_CHECK_ARG(x && out && idx && planes > 0 && N > 0, "plane_max_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((plane_max_fwd_kernel<float>), dim3(planes), dim3(256), 0, st, (const float*)x, out, idx, N),
               hipLaunchKernelGGL((plane_max_fwd_kernel<bf16>), dim3(planes), dim3(256), 0, st, (const bf16*)x, out, idx, N));
   MI_LAUNCH_CHECK();
@@ -544,6 +550,7 @@ extern "C" int mi_pool_pair_bwd(const float* davg, const float* dmax, const int*
                                 void* stream) {
   MI_CHECK_ARG(davg && dmax && idx && dx && planes > 0 && N > 0, "pool_pair_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((pool_pair_bwd_kernel<float>), dim3(planes), dim3(256), 0, st, davg, dmax, idx, (float*)dx, N),
               hipLaunchKernelGGL((pool_pair_bwd_kernel<bf16>), dim3(planes), dim3(256), 0, st, davg, dmax, idx, (bf16*)dx, N));
   MI_LAUNCH_CHECK();
@@ -573,6 +580,7 @@ extern "C" int mi_refine_mix_fwd(const void* low, const void* high, const void* 
                                  int64_t N, int dtype, void* stream) {
   MI_CHECK_ARG(low && high && s && cw && out && B > 0 && C > 0 && N > 0, "refine_mix_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((refine_mix_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)low, (const float*)high, (const float*)s, cw, (float*)out, C, N),
               hipLaunchKernelGGL((refine_mix_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)low, (const bf16*)high, (const bf16*)s, cw, (bf16*)out, C, N));
@@ -583,6 +591,7 @@ extern "C" int mi_refine_mix_bwd(const void* low, const void* high, const void* 
                                  void* dhigh, void* ds, float* dcw, int B, int C, int64_t N, int dtype, void* stream) {
   MI_CHECK_ARG(low && high && s && cw && dout && dlow && dhigh && ds && dcw && B > 0 && C > 0 && N > 0, "refine_mix_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((refine_mix_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)low, (const float*)s, cw, (const float*)dout, (float*)dlow, (float*)dhigh, (float*)ds, C, N),
               hipLaunchKernelGGL((refine_mix_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)low, (const bf16*)s, cw, (const bf16*)dout, (bf16*)dlow, (bf16*)dhigh, (bf16*)ds, C, N));
@@ -597,6 +606,7 @@ extern "C" int mi_scale_add_fwd(const void* a, const void* y, const float* p1, c
                                 int dtype, void* stream) {
   MI_CHECK_ARG(a && y && p1 && p2 && out && B > 0 && C > 0 && N > 0 && B * C <= 65535, "scale_add_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B * C);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((scale_add_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)a, (const float*)y, p1, p2, (float*)out, C, N),
               hipLaunchKernelGGL((scale_add_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)y, p1, p2, (bf16*)out, C, N));
@@ -608,6 +618,7 @@ extern "C" int mi_scale_add_bwd(const void* a, const void* y, const float* p1, c
   MI_CHECK_ARG(a && y && p1 && p2 && dout && da && dy && dp1 && dp2 && B > 0 && C > 0 && N > 0 && B * C <= 65535,
                "scale_add_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(st, K_ADAIR, 0.0, 0.0);
   dim3 grid(cdiv(N, 256), B * C);
   AD_DISPATCH(dtype, hipLaunchKernelGGL((scale_add_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, p1, p2, (float*)da, (float*)dy, C, N),
               hipLaunchKernelGGL((scale_add_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)dout, p1, p2, (bf16*)da, (bf16*)dy, C, N));

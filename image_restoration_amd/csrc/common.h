@@ -206,7 +206,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 enum KernelId {
   K_LN_FWD = 0, K_LN_BWD, K_DW_FWD, K_DW_GATE_FWD, K_DW_BWD_DATA, K_DW_GATE_BWD_DATA, K_DW_WGRAD, K_PW_GEMM, K_GRAM,
   K_GRAM_REDUCE, K_ATTN_FOLD, K_ATTN_BWD_SMALL, K_REDUCE_ROWS, K_CHAN_SUM, K_ADAMW, K_CAST, K_L1, K_PW_PACK, K_GAP,
-  K_IM2COL, K_COL2IM, K_GDFN_FUSED_FWD, K_GDFN_FUSED_BWD, K_MDTA_FUSED_A, K_FUSED_PACK, K_MOE_ROUTE, K_CIRCCONV, K_EWISE, K_CONV3X3, K_GRAM_QK, K_PW_AV, K_BWD_TAIL, K_BWD_TAIL_FIN, K_COUNT
+  K_IM2COL, K_COL2IM, K_GDFN_FUSED_FWD, K_GDFN_FUSED_BWD, K_MDTA_FUSED_A, K_FUSED_PACK, K_MOE_ROUTE, K_CIRCCONV, K_EWISE, K_CONV3X3, K_GRAM_QK, K_PW_AV, K_BWD_TAIL, K_BWD_TAIL_FIN, K_ADAIR, K_COUNT
 };
 // Brackets one kernel launch with two events on ITS stream and books its algorithmic bytes / flops.
 struct ProfScope {

@@ -25,7 +25,7 @@ static std::atomic<int> g_prof_on{0};
 static const char* const g_kernel_names[K_COUNT] = {
     "ln_fwd", "ln_bwd", "dwconv_fwd", "dwconv_gate_fwd", "dwconv_bwd_data", "dwconv_gate_bwd_data", "dwconv_wgrad",
     "pw_gemm", "gram", "gram_reduce", "attn_fold", "attn_bwd_small", "reduce_rows", "chan_sum", "adamw", "cast", "l1_loss",
-    "pw_pack", "gap", "im2col3x3", "col2im3x3", "gdfn_fused_fwd", "gdfn_fused_bwd", "mdta_fused_a", "fused_pack", "moe_route", "patch_circconv", "ewise", "conv3x3", "mdta_qk", "mdta_av", "bwd_tail", "bwd_tail_finish"};
+    "pw_pack", "gap", "im2col3x3", "col2im3x3", "gdfn_fused_fwd", "gdfn_fused_bwd", "mdta_fused_a", "fused_pack", "moe_route", "patch_circconv", "ewise", "conv3x3", "mdta_qk", "mdta_av", "bwd_tail", "bwd_tail_finish", "adair_fre"};
 
 ProfScope::ProfScope(hipStream_t stream, int kernel_id, double bytes, double flops)
     : st(stream), kid(kernel_id), on(g_prof_on.load(std::memory_order_relaxed) != 0) {
