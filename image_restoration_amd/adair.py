@@ -227,54 +227,51 @@ class FreModule(nn.Module):
 
 class AdaIR(nn.Module):
     """The AdaIR network (model.py:378-496): the Restormer U-Net with a FreModule after the latent stage and after decoder
-    levels 3 and 2; same constructor and state_dict keys."""
+    levels 3 and 2; same constructor arguments, registration order and state_dict keys as the reference."""
 
     def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
                  heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type='WithBias', decoder=True):
         super().__init__()
-        f, b, ln = ffn_expansion_factor, bias, LayerNorm_type
+        c1, c2, c3, c4 = (int(dim * 2 ** i) for i in range(4))
+
+        def stage(c, h, n):
+            return _stage(c, h, n, ffn_expansion_factor, bias, LayerNorm_type)
+
         self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
         self.decoder = decoder
-        if self.decoder:
-            self.fre1 = FreModule(dim * 2 ** 3, num_heads=heads[2], bias=bias)
-            self.fre2 = FreModule(dim * 2 ** 2, num_heads=heads[2], bias=bias)
-            self.fre3 = FreModule(dim * 2 ** 1, num_heads=heads[2], bias=bias)
-        self.encoder_level1 = _stage(dim, heads[0], num_blocks[0], f, b, ln)
-        self.down1_2 = Downsample(dim)
-        self.encoder_level2 = _stage(int(dim * 2 ** 1), heads[1], num_blocks[1], f, b, ln)
-        self.down2_3 = Downsample(int(dim * 2 ** 1))
-        self.encoder_level3 = _stage(int(dim * 2 ** 2), heads[2], num_blocks[2], f, b, ln)
-        self.down3_4 = Downsample(int(dim * 2 ** 2))
-        self.latent = _stage(int(dim * 2 ** 3), heads[3], num_blocks[3], f, b, ln)
-        self.up4_3 = Upsample(int(dim * 2 ** 3))
-        self.reduce_chan_level3 = nn.Conv2d(int(dim * 2 ** 3), int(dim * 2 ** 2), kernel_size=1, bias=bias)
-        self.decoder_level3 = _stage(int(dim * 2 ** 2), heads[2], num_blocks[2], f, b, ln)
-        self.up3_2 = Upsample(int(dim * 2 ** 2))
-        self.reduce_chan_level2 = nn.Conv2d(int(dim * 2 ** 2), int(dim * 2 ** 1), kernel_size=1, bias=bias)
-        self.decoder_level2 = _stage(int(dim * 2 ** 1), heads[1], num_blocks[1], f, b, ln)
-        self.up2_1 = Upsample(int(dim * 2 ** 1))
-        self.decoder_level1 = _stage(int(dim * 2 ** 1), heads[0], num_blocks[0], f, b, ln)
-        self.refinement = _stage(int(dim * 2 ** 1), heads[0], num_refinement_blocks, f, b, ln)
-        self.output = nn.Conv2d(int(dim * 2 ** 1), out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        if decoder:                                   # the three frequency modules all take heads[2] (model.py:402-404)
+            for name, c in (("fre1", c4), ("fre2", c3), ("fre3", c2)):
+                setattr(self, name, FreModule(c, num_heads=heads[2], bias=bias))
+        self.encoder_level1, self.down1_2 = stage(c1, heads[0], num_blocks[0]), Downsample(c1)
+        self.encoder_level2, self.down2_3 = stage(c2, heads[1], num_blocks[1]), Downsample(c2)
+        self.encoder_level3, self.down3_4 = stage(c3, heads[2], num_blocks[2]), Downsample(c3)
+        self.latent = stage(c4, heads[3], num_blocks[3])
+        self.up4_3 = Upsample(c4)
+        self.reduce_chan_level3 = nn.Conv2d(c4, c3, kernel_size=1, bias=bias)
+        self.decoder_level3 = stage(c3, heads[2], num_blocks[2])
+        self.up3_2 = Upsample(c3)
+        self.reduce_chan_level2 = nn.Conv2d(c3, c2, kernel_size=1, bias=bias)
+        self.decoder_level2 = stage(c2, heads[1], num_blocks[1])
+        self.up2_1 = Upsample(c2)
+        self.decoder_level1 = stage(c2, heads[0], num_blocks[0])
+        self.refinement = stage(c2, heads[0], num_refinement_blocks)
+        self.output = nn.Conv2d(c2, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
 
     def forward(self, inp_img, noise_emb=None):
-        inp_enc_level1 = self.patch_embed(inp_img)
-        out_enc_level1 = self.encoder_level1(inp_enc_level1)
-        out_enc_level2 = self.encoder_level2(self.down1_2(out_enc_level1))
-        out_enc_level3 = self.encoder_level3(self.down2_3(out_enc_level2))
-        latent = self.latent(self.down3_4(out_enc_level3))
+        def merge(up, deep, skip, reduce):            # concat-free: the two halves are the K panels of one 1x1 GEMM
+            return _apply(_Conv1x1Fn, up(deep), skip, reduce.weight, reduce.bias)
+
+        e1 = self.encoder_level1(self.patch_embed(inp_img))
+        e2 = self.encoder_level2(self.down1_2(e1))
+        e3 = self.encoder_level3(self.down2_3(e2))
+        z = self.latent(self.down3_4(e3))
         if self.decoder:
-            latent = self.fre1(inp_img, latent)
-        inp_dec_level3 = _apply(_Conv1x1Fn, self.up4_3(latent), out_enc_level3, self.reduce_chan_level3.weight,
-                                self.reduce_chan_level3.bias)
-        out_dec_level3 = self.decoder_level3(inp_dec_level3)
+            z = self.fre1(inp_img, z)
+        z = self.decoder_level3(merge(self.up4_3, z, e3, self.reduce_chan_level3))
         if self.decoder:
-            out_dec_level3 = self.fre2(inp_img, out_dec_level3)
-        inp_dec_level2 = _apply(_Conv1x1Fn, self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
-                                self.reduce_chan_level2.bias)
-        out_dec_level2 = self.decoder_level2(inp_dec_level2)
+            z = self.fre2(inp_img, z)
+        z = self.decoder_level2(merge(self.up3_2, z, e2, self.reduce_chan_level2))
         if self.decoder:
-            out_dec_level2 = self.fre3(inp_img, out_dec_level2)
-        inp_dec_level1 = _up_cat(self.up2_1, out_dec_level2, out_enc_level1)
-        out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
-        return _conv2d(out_dec_level1, self.output, inp_img)
+            z = self.fre3(inp_img, z)
+        z = self.refinement(self.decoder_level1(_up_cat(self.up2_1, z, e1)))
+        return _conv2d(z, self.output, inp_img)
