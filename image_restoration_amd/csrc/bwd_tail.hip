@@ -270,10 +270,18 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       s1 += gv[j];
       s2 += gv[j] * xv[j];
     }
-#pragma unroll
-    for (int o = 1; o < LPP; o <<= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
+    // sum over the LPP consecutive lanes of this pixel, every lane gets the total: DPP only (quad swaps, then the half-row
+    // mirror adds the other quad's total) - no ds_bpermute round trips on the phase's critical path
+    auto dpp = [](float v, auto ctrl) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    s1 += dpp(s1, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    s2 += dpp(s2, std::integral_constant<int, 0xB1>{});
+    s1 += dpp(s1, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    s2 += dpp(s2, std::integral_constant<int, 0x4E>{});
+    if (LPP == 8) {
+      s1 += dpp(s1, std::integral_constant<int, 0x141>{});  // row_half_mirror
+      s2 += dpp(s2, std::integral_constant<int, 0x141>{});
     }
     const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
 #pragma unroll
