@@ -89,6 +89,16 @@ def test_moce_and_adair_state_dict_keys_match_reference(lib):
     assert list(ad.Chanel_Cross_Attention(48, 4, False).state_dict()) == [str(k) for k in gold["adair_cross"]]
     with pytest.raises(RuntimeError, match="MI355X only"):
         mo.CrossAttention(48, 1, True)(torch.zeros(1, 48, 8, 8), torch.zeros(1, 48, 8, 8))
+    # AdaIR: the whole network and its frequency module (tools/capture_golden_adair.py), MoCE-IR whole network
+    from image_restoration_amd import configs
+    from oracle import adair_ref as A
+    akeys = load("adair_keys")
+    net = ad.AdaIR(**configs.ADAIR_BASE)
+    assert list(net.state_dict()) == [str(k) for k in akeys["adair_base"]]
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == A.adair_param_shapes(configs.ADAIR_BASE)
+    assert list(ad.FreModule(48, 4, False).state_dict()) == [str(k) for k in akeys["fre"]]
+    with pytest.raises(RuntimeError):
+        ad.FreModule(32, 2, False)(torch.zeros(1, 3, 32, 32), torch.zeros(1, 32, 8, 8))      # CPU tensors: no fallback
 
 
 def test_product_never_imports_oracle():
