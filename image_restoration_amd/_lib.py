@@ -25,7 +25,8 @@ class PwDesc(C.Structure):
                 ("r", vp), ("r_bs", c_i64), ("r_gs", c_i64),
                 ("y", vp), ("y_bs", c_i64), ("y_gs", c_i64),
                 ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int),
-                ("ln_w", fp), ("ln_b", fp), ("ln_mean", fp), ("ln_rstd", fp), ("ln_mode", C.c_int)]
+                ("ln_w", fp), ("ln_b", fp), ("ln_mean", fp), ("ln_rstd", fp), ("ln_mode", C.c_int),
+                ("f8", C.c_int), ("f8_sx", C.c_float), ("f8_sw", C.c_float)]
 
 
 class GramDesc(C.Structure):
@@ -84,6 +85,10 @@ class LnHead(C.Structure):
     _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("with_bias", C.c_int)]
 
 
+class F8Scales(C.Structure):
+    _fields_ = [("x1", C.c_float), ("w1", C.c_float), ("x2", C.c_float), ("w2", C.c_float)]
+
+
 class LnTail(C.Structure):
     _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("dres", vp), ("dw", fp), ("db", fp)]
 
@@ -135,6 +140,13 @@ SIGNATURES = {
     "mi_mdta_fwd_ln": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
     "mi_gdfn_fwd_ln_ok": (C.c_int, [C.POINTER(GdfnShape)]),
     "mi_gdfn_fwd_ln": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
+    "mi_pw_gemm_f8_ok": (C.c_int, [C.POINTER(PwDesc)]),
+    "mi_mdta_fwd_f8_ok": (C.c_int, [C.POINTER(MdtaShape), C.c_int]),
+    "mi_mdta_fwd_f8": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnHead), C.POINTER(F8Scales), vp, vp, vp,
+                                 vp, vp]),
+    "mi_gdfn_fwd_f8_ok": (C.c_int, [C.POINTER(GdfnShape), C.c_int]),
+    "mi_gdfn_fwd_f8": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnHead), C.POINTER(F8Scales), vp, vp, vp,
+                                 vp, vp]),
     "mi_box_down": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_fre_rect": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_fre_split_coef_bytes": (C.c_size_t, [C.c_int, C.c_int]),

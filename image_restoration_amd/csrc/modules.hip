@@ -164,7 +164,7 @@ static size_t attn_pw_ws_bytes(const AttnDims& d) {
 // out = (residual?) + project_out(softmax(temperature * q^ k^T) v)        Restormer.py:121-131
 static int attn_core_fwd(const AttnDims& d, const QkvView& v, const float* temperature, const float* proj_w,
                          const float* proj_b, const void* residual, void* out, const AttnSaved& sv, const AttnScratch& w,
-                         void* stream) {
+                         void* stream, const mi_f8_scales* f8 = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   mi_gram_desc g = attn_qk_gram(d, v, w.graw, w.ss);
   MI_TRY(mi_gram(&g, w.gram_ws, stream));
@@ -172,6 +172,7 @@ static int attn_core_fwd(const AttnDims& d, const QkvView& v, const float* tempe
   mi_pw_desc d2 = conv1x1(v.v, d.C, sv.M, false, d.C, proj_b, residual, out, d.C, d.B, d.N, d.dtype);
   d2.x1_bs = v.v_bs;
   d2.w_bs = (int64_t)d.C * d.C;
+  if (f8) { d2.f8 = 1; d2.f8_sx = f8->x2; d2.f8_sw = f8->w2; }
   return mi_pw_gemm(&d2, w.pw_ws, stream);
 }
 
@@ -397,7 +398,7 @@ static int ln_head_check(const mi_ln_head* ln, const char* who) {
   return MI_OK;
 }
 static int mdta_fwd_impl(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* residual, void* out,
-                         void* saved, void* ws, void* stream, const mi_ln_head* ln) {
+                         void* saved, void* ws, void* stream, const mi_ln_head* ln, const mi_f8_scales* f8 = nullptr) {
   MI_TRY(mdta_check(s));
   MI_CHECK_ARG(p && x && out && ws, "mdta_fwd: null pointer");
   MI_CHECK_ARG(p->temperature && p->qkv_w && p->dw_w && p->proj_w, "mdta_fwd: null parameter");
@@ -408,10 +409,11 @@ static int mdta_fwd_impl(const mi_mdta_shape* s, const mi_mdta_params* p, const 
   // qkv0 = qkv(x);  qkv = dw(qkv0)                               Restormer.py:114
   mi_pw_desc d1 = conv1x1(x, C, p->qkv_w, false, C, p->qkv_b, nullptr, sv.qkv0, 3 * C, B, N, dt);
   ln_head_apply(&d1, ln);
+  if (f8) { d1.f8 = 1; d1.f8_sx = f8->x1; d1.f8_sw = f8->w1; }
   MI_TRY(mi_pw_gemm(&d1, w.at.pw_ws, stream));
   MI_TRY(mi_dwconv_fwd(sv.qkv0, p->dw_w, p->dw_b, sv.qkv, B, 3 * C, s->H, s->W, s->ks, dt, stream));
   return attn_core_fwd(mdta_dims(s), mdta_view(s, sv.qkv), p->temperature, p->proj_w, p->proj_b, residual, out, sv.at, w.at,
-                       stream);
+                       stream, f8);
 }
 extern "C" int mi_mdta_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* x, const void* residual, void* out,
                            void* saved, void* ws, void* stream) {
@@ -428,6 +430,29 @@ extern "C" int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, c
   MI_TRY(ln_head_check(ln, "mdta_fwd_ln"));
   MI_CHECK_ARG(mi_mdta_fwd_ln_ok(s), "mdta_fwd_ln: shape not covered (bf16, C <= 96, H*W %% 64 == 0)");
   return mdta_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
+}
+
+// fp8 MFMA operands in both projections (inference: nothing is saved).  ln may be NULL (x is then the LayerNorm output).
+static int f8_check(const mi_f8_scales* f, const char* who) {
+  MI_CHECK_ARG(f && f->x1 > 0.f && f->w1 > 0.f && f->x2 > 0.f && f->w2 > 0.f, "%s: fp8 scales must be positive", who);
+  return MI_OK;
+}
+extern "C" int mi_mdta_fwd_f8_ok(const mi_mdta_shape* s, int with_ln) {
+  if (mdta_check(s) != MI_OK || s->dtype != MI_BF16) return 0;
+  const int64_t N = (int64_t)s->H * s->W;
+  mi_pw_desc d1 = conv1x1((void*)256, s->C, (const float*)256, false, s->C, nullptr, nullptr, (void*)256, 3 * s->C, s->B, N, s->dtype);
+  mi_pw_desc d2 = conv1x1((void*)256, s->C, (const float*)256, false, s->C, nullptr, (void*)256, (void*)256, s->C, s->B, N, s->dtype);
+  d2.x1_bs = 3 * (int64_t)s->C * N;
+  d2.w_bs = (int64_t)s->C * s->C;
+  if (with_ln && !mi_pw_gemm_ln_ok(&d1)) return 0;
+  return mi_pw_gemm_f8_ok(&d1) && mi_pw_gemm_f8_ok(&d2);
+}
+extern "C" int mi_mdta_fwd_f8(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const mi_f8_scales* f8,
+                              const void* x, const void* residual, void* out, void* ws, void* stream) {
+  MI_TRY(f8_check(f8, "mdta_fwd_f8"));
+  if (ln) MI_TRY(ln_head_check(ln, "mdta_fwd_f8"));
+  MI_CHECK_ARG(mi_mdta_fwd_f8_ok(s, ln != nullptr), "mdta_fwd_f8: shape not covered (bf16, both projections on a wave-owned form)");
+  return mdta_fwd_impl(s, p, x, residual, out, nullptr, ws, stream, ln, f8);
 }
 
 // ln == nullptr: x is the conv input (LayerNorm OUTPUT) and dx its gradient.  ln != nullptr: x is the LayerNorm INPUT; the
@@ -558,7 +583,7 @@ extern "C" size_t mi_gdfn_workspace(const mi_gdfn_shape* s) {
 }
 
 static int gdfn_fwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* residual, void* out,
-                         void* saved, void* ws, void* stream, const mi_ln_head* ln) {
+                         void* saved, void* ws, void* stream, const mi_ln_head* ln, const mi_f8_scales* f8 = nullptr) {
   MI_TRY(gdfn_check(s));
   MI_CHECK_ARG(p && x && out && ws, "gdfn_fwd: null pointer");
   MI_CHECK_ARG(p->in_w && p->dw_w && p->out_w, "gdfn_fwd: null parameter");
@@ -568,10 +593,12 @@ static int gdfn_fwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const 
   GdfnSaved sv = saved ? gdfn_saved_layout(s, saved) : w.inf;
   mi_pw_desc d1 = conv1x1(x, C, p->in_w, false, C, p->in_b, nullptr, sv.h0, 2 * h, B, N, dt);       // Restormer.py:89
   ln_head_apply(&d1, ln);
+  if (f8) { d1.f8 = 1; d1.f8_sx = f8->x1; d1.f8_sw = f8->w1; }
   MI_TRY(mi_pw_gemm(&d1, w.pw_ws, stream));
   MI_TRY(mi_dwconv_gate_fwd(sv.h0, p->dw_w, p->dw_b, (saved && !gdfn_recompute(s)) ? sv.h1 : nullptr, sv.g, B, 2 * h, s->H,
                             s->W, s->ks, dt, stream));                                               // :90-91
   mi_pw_desc d2 = conv1x1(sv.g, h, p->out_w, false, h, p->out_b, residual, out, C, B, N, dt);       // :92
+  if (f8) { d2.f8 = 1; d2.f8_sx = f8->x2; d2.f8_sw = f8->w2; }
   MI_TRY(mi_pw_gemm(&d2, w.pw_ws, stream));
   return MI_OK;
 }
@@ -590,6 +617,22 @@ extern "C" int mi_gdfn_fwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, c
   MI_TRY(ln_head_check(ln, "gdfn_fwd_ln"));
   MI_CHECK_ARG(mi_gdfn_fwd_ln_ok(s), "gdfn_fwd_ln: shape not covered (bf16, C <= 96, H*W %% 64 == 0)");
   return gdfn_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
+}
+
+extern "C" int mi_gdfn_fwd_f8_ok(const mi_gdfn_shape* s, int with_ln) {
+  if (gdfn_check(s) != MI_OK || s->dtype != MI_BF16) return 0;
+  const int64_t N = (int64_t)s->H * s->W;
+  mi_pw_desc d1 = conv1x1((void*)256, s->C, (const float*)256, false, s->C, nullptr, nullptr, (void*)256, 2 * s->hidden, s->B, N, s->dtype);
+  mi_pw_desc d2 = conv1x1((void*)256, s->hidden, (const float*)256, false, s->hidden, nullptr, (void*)256, (void*)256, s->C, s->B, N, s->dtype);
+  if (with_ln && !mi_pw_gemm_ln_ok(&d1)) return 0;
+  return mi_pw_gemm_f8_ok(&d1) && mi_pw_gemm_f8_ok(&d2);
+}
+extern "C" int mi_gdfn_fwd_f8(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const mi_f8_scales* f8,
+                              const void* x, const void* residual, void* out, void* ws, void* stream) {
+  MI_TRY(f8_check(f8, "gdfn_fwd_f8"));
+  if (ln) MI_TRY(ln_head_check(ln, "gdfn_fwd_f8"));
+  MI_CHECK_ARG(mi_gdfn_fwd_f8_ok(s, ln != nullptr), "gdfn_fwd_f8: shape not covered (bf16, both projections on a wave-owned form)");
+  return gdfn_fwd_impl(s, p, x, residual, out, nullptr, ws, stream, ln, f8);
 }
 
 static int gdfn_bwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,

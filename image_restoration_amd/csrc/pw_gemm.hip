@@ -108,6 +108,7 @@ struct PwG {
   int wp_per_batch, wp_per_group, k_chunks;
   // LayerNorm of X applied on the way in (xres form only): gamma / beta [K], statistics out [batch][n] (or null)
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;   // 0 none, 1 WithBias, 2 BiasFree
+  float f8_sx, f8_sw;       // fp8 operand forms: X / f8_sx and W / f8_sw are rounded to e4m3, the accumulator is scaled by their product
 };
 
 // X chunk addressing in LDS.  Register-staged image: [32][PW_XS] padded rows.  LDS-DMA image: [32][64] unpadded rows
@@ -606,6 +607,34 @@ __device__ __forceinline__ s16x8 pww_w_frag(const bf16* wr) {
   const s16x4 lo = *reinterpret_cast<const s16x4*>(wr), hi = *reinterpret_cast<const s16x4*>(wr + 16);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// MFMA operand policy of the wave-owned kernels.  bf16: fragments go to v_mfma_f32_16x16x32_bf16 as they are.  fp8 (mi_pw_desc.f8):
+// the SAME fragments (8 bf16 along k per lane) are divided by a power-of-two scale and rounded to OCP e4m3 in registers - four
+// v_cvt_scalef32_pk_fp8_bf16 per fragment, element e to byte e for A and B alike, so the k-slot order carries over - and go to
+// v_mfma_f32_16x16x32_fp8_fp8.  X is converted once per tile, W once per use (it stays bf16 in LDS).  The conversion returns NaN
+// past +-448 unless MODE.FP16_OVFL is set (measured: tools/microbench/f8_probe.hip): the fp8 kernels set it, so a scale that is
+// too small saturates instead of poisoning the image.
+template <bool F8> struct PwwOp;
+template <> struct PwwOp<false> {
+  using Frag = s16x8;
+  static __device__ __forceinline__ void enter() {}
+  static __device__ __forceinline__ Frag cvt(const s16x8 v, float) { return v; }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct PwwOp<true> {
+  using Frag = long;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }   // MODE.FP16_OVFL = 1
+  static __device__ __forceinline__ Frag cvt(const s16x8 v, float scale) {
+    s16x2_t lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[0], v[1]}), scale, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[2], v[3]}), scale, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[4], v[5]}), scale, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[6], v[7]}), scale, true);
+    return (long)(unsigned long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+};
 // packed weight image of this workgroup's slice -> LDS, chunk images back to back ([tile][chunk][tm][WS_ROW])
 __device__ __forceinline__ void pww_stage_weights(bf16* Wl, const bf16* wpk, int images, int tm, int chunk_stride_elems, int t) {
   const int vpc = tm * PwRow<bf16>::WS_ROW / 8;
@@ -758,8 +787,10 @@ __device__ __forceinline__ void pww_ln_inplace(u32x4 (&raw)[KB][4], int ktot, co
   }
 }
 
-template <int KB>
+template <int KB, bool F8>
 __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, int m_tiles, int tiles_per_wave, int chunk_stride_elems) {
+  using Op = PwwOp<F8>;
+  Op::enter();
   const PwK& p = q.k;
   constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -805,9 +836,14 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
     if (q.ln_mode)
       pww_ln_inplace<KB>(raw, x.ktot, lnp, q.ln_mode, q.ln_mean ? q.ln_mean + zb * p.n + n0 : nullptr,
                          q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, ln);
-    s16x8 a[KB][4];
+    typename Op::Frag a[KB][4];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) pww_chunk_to_frags(a[kb], raw[kb], patch, kb, x.ktot, ln);
+    for (int kb = 0; kb < KB; ++kb) {
+      s16x8 a16[4];
+      pww_chunk_to_frags(a16, raw[kb], patch, kb, x.ktot, ln);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) a[kb][nf] = Op::cvt(a16[nf], q.f8_sx);
+    }
     if (tt + 1 < tiles_per_wave && tile + 1 < n_tiles) {             // the next tile's X flies while this tile's channels are computed
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) pww_load_chunk(raw[kb], x, kb, n0 + PW_TN, ln);
@@ -825,10 +861,17 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          const s16x8 b = pww_w_frag(wt + (kb * TM + 16 * f) * WS_ROW);
+          const typename Op::Frag b = Op::cvt(pww_w_frag(wt + (kb * TM + 16 * f) * WS_ROW), q.f8_sw);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) acc[f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][nf], b, acc[f][nf], 0, 0, 0);
+          for (int nf = 0; nf < 4; ++nf) acc[f][nf] = Op::mma(a[kb][nf], b, acc[f][nf]);
         }
+      if (F8) {
+        const float os = q.f8_sx * q.f8_sw;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) acc[f][nf] *= os;
+      }
       if (!o.r) {
         pww_store_bf16<2>(acc[0], acc[1], patch, o, mbase, n0, ln);
       } else {                                                       // (no model shape takes this branch: wide outputs carry no residual)
@@ -842,8 +885,10 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   }
 }
 
-template <int MF>
+template <int MF, bool F8>
 __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q, int tiles_per_wave, int chunk_stride_elems) {
+  using Op = PwwOp<F8>;
+  Op::enter();
   const PwK& p = q.k;
   constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 16 * MF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -886,27 +931,40 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
     if (nchunks > 1) pww_load_chunk(r1, x, 1, n0, ln);
     for (int kb = 0; kb < nchunks; kb += 2) {
       {
-        s16x8 a[4];
-        pww_chunk_to_frags(a, r0, patch, kb, x.ktot, ln);
+        s16x8 a16[4];
+        pww_chunk_to_frags(a16, r0, patch, kb, x.ktot, ln);
         if (kb + 2 < nchunks) pww_load_chunk(r0, x, kb + 2, n0, ln);
+        typename Op::Frag a[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) a[nf] = Op::cvt(a16[nf], q.f8_sx);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          const s16x8 b = pww_w_frag(wl + (kb * TM + 16 * mf) * WS_ROW);
+          const typename Op::Frag b = Op::cvt(pww_w_frag(wl + (kb * TM + 16 * mf) * WS_ROW), q.f8_sw);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b, acc[mf][nf], 0, 0, 0);
+          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = Op::mma(a[nf], b, acc[mf][nf]);
         }
       }
       if (kb + 1 < nchunks) {
-        s16x8 a[4];
-        pww_chunk_to_frags(a, r1, patch, kb + 1, x.ktot, ln);
+        s16x8 a16[4];
+        pww_chunk_to_frags(a16, r1, patch, kb + 1, x.ktot, ln);
         if (kb + 3 < nchunks) pww_load_chunk(r1, x, kb + 3, n0, ln);
+        typename Op::Frag a[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) a[nf] = Op::cvt(a16[nf], q.f8_sx);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          const s16x8 b = pww_w_frag(wl + ((kb + 1) * TM + 16 * mf) * WS_ROW);
+          const typename Op::Frag b = Op::cvt(pww_w_frag(wl + ((kb + 1) * TM + 16 * mf) * WS_ROW), q.f8_sw);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nf], b, acc[mf][nf], 0, 0, 0);
+          for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = Op::mma(a[nf], b, acc[mf][nf]);
         }
       }
+    }
+    if (F8) {
+      const float os = q.f8_sx * q.f8_sw;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] *= os;
     }
     if (!o.r) {
 #pragma unroll
@@ -1076,6 +1134,11 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   q.k = k; q.ws = cached ? cached : (const unsigned char*)ws; q.wp_slice = pl.slice_elems; q.wp_per_batch = pl.per_batch;
   q.wp_per_group = pl.per_group; q.k_chunks = pl.k_chunks;
   q.ln_w = d->ln_w; q.ln_b = d->ln_b; q.ln_mean = d->ln_mean; q.ln_rstd = d->ln_rstd; q.ln_mode = d->ln_mode;
+  q.f8_sx = d->f8_sx; q.f8_sw = d->f8_sw;
+  if (d->f8) {
+    MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: fp8 operands need a wave-owned bf16 form (mi_pw_gemm_f8_ok)");
+    MI_CHECK_ARG(d->f8_sx > 0.f && d->f8_sw > 0.f, "pw_gemm: fp8 operand scales must be positive (powers of two)");
+  }
   if (d->ln_mode) {
     MI_CHECK_ARG(pl.wave == 1 && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
                      (d->ln_mode == 1 || d->ln_mode == 2) && (d->ln_mean == nullptr) == (d->ln_rstd == nullptr),
@@ -1113,14 +1176,22 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(KERNEL, wgrid, wblock, lds, st, q, __VA_ARGS__);                                                      \
   } while (0)
-      if (pl.wave == 1) {
-        if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1>), pl.m_tiles, (int)tpw, pl.chunk_elems);
-        else if (pl.k_chunks == 2) PWW_LAUNCH((pw_gemm_wave_xres_kernel<2>), pl.m_tiles, (int)tpw, pl.chunk_elems);
-        else PWW_LAUNCH((pw_gemm_wave_xres_kernel<3>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+      if (pl.wave == 1 && !d->f8) {
+        if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else if (pl.k_chunks == 2) PWW_LAUNCH((pw_gemm_wave_xres_kernel<2, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_xres_kernel<3, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+      } else if (pl.wave == 1) {
+        if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1, true>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else if (pl.k_chunks == 2) PWW_LAUNCH((pw_gemm_wave_xres_kernel<2, true>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_xres_kernel<3, true>), pl.m_tiles, (int)tpw, pl.chunk_elems);
+      } else if (!d->f8) {
+        if (pl.tm == 96) PWW_LAUNCH((pw_gemm_wave_stream_kernel<6, false>), (int)tpw, pl.chunk_elems);
+        else if (pl.tm == 64) PWW_LAUNCH((pw_gemm_wave_stream_kernel<4, false>), (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_stream_kernel<3, false>), (int)tpw, pl.chunk_elems);
       } else {
-        if (pl.tm == 96) PWW_LAUNCH((pw_gemm_wave_stream_kernel<6>), (int)tpw, pl.chunk_elems);
-        else if (pl.tm == 64) PWW_LAUNCH((pw_gemm_wave_stream_kernel<4>), (int)tpw, pl.chunk_elems);
-        else PWW_LAUNCH((pw_gemm_wave_stream_kernel<3>), (int)tpw, pl.chunk_elems);
+        if (pl.tm == 96) PWW_LAUNCH((pw_gemm_wave_stream_kernel<6, true>), (int)tpw, pl.chunk_elems);
+        else if (pl.tm == 64) PWW_LAUNCH((pw_gemm_wave_stream_kernel<4, true>), (int)tpw, pl.chunk_elems);
+        else PWW_LAUNCH((pw_gemm_wave_stream_kernel<3, true>), (int)tpw, pl.chunk_elems);
       }
 #undef PWW_LAUNCH
     }
@@ -1205,6 +1276,11 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
 extern "C" int mi_pw_gemm_ln_ok(const mi_pw_desc* d) {
   if (!d || pw_check(d) != MI_OK || d->k2 != 0 || d->groups != 1) return 0;
   return pw_plan(d).wave == 1 ? 1 : 0;
+}
+
+extern "C" int mi_pw_gemm_f8_ok(const mi_pw_desc* d) {
+  if (!d || pw_check(d) != MI_OK || d->dtype != MI_BF16) return 0;
+  return pw_plan(d).wave != 0 ? 1 : 0;
 }
 
 extern "C" int mi_pw_cache_enable(void* buf, size_t bytes, const void* params_lo, const void* params_hi) {

@@ -27,6 +27,33 @@ def crop_to_multiple(img: torch.Tensor, base: int = 16) -> torch.Tensor:
     return img[..., ch // 2:h - ch + ch // 2, cw // 2:w - cw + cw // 2]
 
 
+def _cells(img: torch.Tensor, tile: int, overlap: int, dtype):
+    B, C, H0, W0 = img.shape
+    x = img.to(dtype) if dtype is not None else img
+    H, W = -(-H0 // tile) * tile, -(-W0 // tile) * tile
+    xp = F.pad(x, (overlap, overlap + W - W0, overlap, overlap + H - H0), mode="replicate")
+    cells = [(b, i, j) for b in range(B) for i in range(H // tile) for j in range(W // tile)]
+    return xp, cells, H, W
+
+
+@torch.no_grad()
+def calibrate_fp8(model, img: torch.Tensor, tile: int = 224, overlap: int = 16, max_tiles: int = 8,
+                  dtype: Optional[torch.dtype] = torch.bfloat16) -> None:
+    """Static activation scales for the fp8 projections (restormer.fp8_calibrate) from up to ``max_tiles`` cells spread over
+    ``img``; afterwards ``restormer.fp8_projections(model, "all" | "attn")`` switches the no_grad forward over."""
+    from . import restormer
+    xp, cells, _, _ = _cells(img, tile, overlap, dtype)
+    size = tile + 2 * overlap
+    pick = cells[::max(1, len(cells) // max_tiles)][:max_tiles]
+    batch = torch.stack([xp[b, :, i * tile:i * tile + size, j * tile:j * tile + size] for b, i, j in pick]).contiguous()
+    was_training = model.training
+    model.eval()
+    try:
+        restormer.fp8_calibrate(model, [batch])
+    finally:
+        model.train(was_training)
+
+
 @torch.no_grad()
 def tiled_restore(model, img: torch.Tensor, tile: int = 224, overlap: int = 16, tile_batch: int = 8,
                   dtype: Optional[torch.dtype] = torch.bfloat16) -> torch.Tensor:
@@ -35,12 +62,9 @@ def tiled_restore(model, img: torch.Tensor, tile: int = 224, overlap: int = 16, 
     native 3x3 glue and the fused LN + GDFN kernels are built for.  H, W need not be multiples of ``tile``: the image is
     edge-replicated up to the cell grid and the result cropped back."""
     B, C, H0, W0 = img.shape
-    x = img.to(dtype) if dtype is not None else img
-    H, W = -(-H0 // tile) * tile, -(-W0 // tile) * tile
-    xp = F.pad(x, (overlap, overlap + W - W0, overlap, overlap + H - H0), mode="replicate")
+    xp, cells, H, W = _cells(img, tile, overlap, dtype)
     size = tile + 2 * overlap
-    cells = [(b, i, j) for b in range(B) for i in range(H // tile) for j in range(W // tile)]
-    out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+    out = torch.empty((B, C, H, W), dtype=xp.dtype, device=xp.device)
     was_training = model.training
     model.eval()
     try:

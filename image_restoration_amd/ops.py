@@ -167,9 +167,11 @@ def dwconv_gate_bwd_recompute(dg: Tensor, x: Tensor, w: Tensor, bias: Optional[T
 
 
 def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-            transposed: bool = False, x2: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+            transposed: bool = False, x2: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            f8: Optional[Tuple[float, float]] = None) -> Tensor:
     """y = W x (+bias)(+residual).  x [B,K,H,W]; w [M,K(,1,1)] or, transposed, [K,M(,1,1)] used as W^T.
-    x2: optional second K-panel (channel concat without the concat)."""
+    x2: optional second K-panel (channel concat without the concat).  f8 = (sx, sw): fp8 e4m3 MFMA operands (x / sx, w / sw,
+    powers of two; bf16 tensors, wave-owned kernel forms only - the call fails elsewhere)."""
     _gpu(x, w, bias, residual, x2)
     _f32(w, "1x1 weight"); _f32(bias, "1x1 bias")
     B, K1, H, W = x.shape
@@ -189,6 +191,8 @@ def conv1x1(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     d.r, d.r_bs, d.r_gs = _p(residual), M * N, 0
     d.y, d.y_bs, d.y_gs = _p(y), M * N, 0
     d.m, d.n, d.batch, d.groups, d.dtype = M, N, B, 1, _dt(x)
+    if f8 is not None:
+        d.f8, d.f8_sx, d.f8_sw = 1, float(f8[0]), float(f8[1])
     pw_gemm_desc(d, x.device)
     return y
 
@@ -258,16 +262,37 @@ def mdta_fwd_ln_ok(x: Tensor, heads: int, ks: int) -> bool:
     return bool(L.lib().mi_mdta_fwd_ln_ok(C.byref(s)))
 
 
+F8ScalesT = Tuple[float, float, float, float]       # x1, w1 (first projection: input, weight), x2, w2 (second projection)
+
+
+def mdta_fwd_f8_ok(x: Tensor, heads: int, ks: int, with_ln: bool) -> bool:
+    """Can both MDTA projections run on fp8 MFMA operands (mi_mdta_fwd_f8)?"""
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        return False
+    s = _mdta_shape(x, heads, ks)
+    return bool(L.lib().mi_mdta_fwd_f8_ok(C.byref(s), int(with_ln)))
+
+
 def mdta_fwd(x: Tensor, residual: Optional[Tensor], params: MdtaParamsT, heads: int, need_saved: bool,
-             ln: Optional[LnHeadT] = None):
+             ln: Optional[LnHeadT] = None, f8: Optional[F8ScalesT] = None):
     """params = (temperature, qkv.weight, qkv.bias, qkv_dwconv.weight, qkv_dwconv.bias, project_out.weight, .bias).
     ln = (weight, bias, want_stats): x is the LayerNorm INPUT and the norm runs inside the qkv GEMM; returns
-    (out, saved, mean, rstd) then."""
+    (out, saved, mean, rstd) then.  f8 = (x1, w1, x2, w2): inference with fp8 e4m3 MFMA operands in both projections
+    (nothing saved, no statistics); returns out."""
     _gpu(x, residual, *params)
     ks = params[3].shape[-1]
     s = _mdta_shape(x, heads, ks)
     lib = L.lib()
     out = torch.empty_like(x)
+    if f8 is not None:
+        if need_saved or (ln is not None and ln[2]):
+            raise ValueError("fp8 projections are an inference path: nothing can be saved")
+        ws = _ws(lib.mi_mdta_workspace(C.byref(s)), x.device)
+        lh = _ln_head(ln, x)[0] if ln is not None else None
+        L.check(lib.mi_mdta_fwd_f8(C.byref(s), C.byref(_mdta_params(params)), C.byref(lh) if lh is not None else None,
+                                   C.byref(L.F8Scales(*[float(v) for v in f8])), _p(x), _p(residual), _p(out), _p(ws),
+                                   _stream()), "mdta_fwd_f8")
+        return out
     saved = _blob(lib.mi_mdta_saved_bytes(C.byref(s)), x.device) if need_saved else None
     ws = _ws(lib.mi_mdta_workspace(C.byref(s)), x.device)
     pp = _mdta_params(params)
@@ -379,12 +404,32 @@ def gdfn_fwd_ln_ok(x: Tensor, hidden: int, ks: int) -> bool:
     return bool(L.lib().mi_gdfn_fwd_ln_ok(C.byref(s)))
 
 
-def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool, ln: Optional[LnHeadT] = None):
-    """params = (project_in.weight, .bias, dwconv.weight, .bias, project_out.weight, .bias).  ln: as in mdta_fwd."""
+def gdfn_fwd_f8_ok(x: Tensor, hidden: int, ks: int, with_ln: bool) -> bool:
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        return False
+    s = _gdfn_shape(x, hidden, ks, 0)
+    return bool(L.lib().mi_gdfn_fwd_f8_ok(C.byref(s), int(with_ln)))
+
+
+def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_saved: bool, ln: Optional[LnHeadT] = None,
+             f8: Optional[F8ScalesT] = None):
+    """params = (project_in.weight, .bias, dwconv.weight, .bias, project_out.weight, .bias).  ln, f8: as in mdta_fwd."""
     _gpu(x, residual, *params)
     for t in params:
         _f32(t, "GDFN parameter")
     hidden, ks = params[4].shape[1], params[2].shape[-1]
+    if f8 is not None:
+        if need_saved or (ln is not None and ln[2]):
+            raise ValueError("fp8 projections are an inference path: nothing can be saved")
+        s = _gdfn_shape(x, hidden, ks, 0)
+        lib = L.lib()
+        out = torch.empty_like(x)
+        ws = _ws(lib.mi_gdfn_workspace(C.byref(s)), x.device)
+        lh = _ln_head(ln, x)[0] if ln is not None else None
+        L.check(lib.mi_gdfn_fwd_f8(C.byref(s), C.byref(L.GdfnParams(*[_p(t) for t in params])),
+                                   C.byref(lh) if lh is not None else None, C.byref(L.F8Scales(*[float(v) for v in f8])),
+                                   _p(x), _p(residual), _p(out), _p(ws), _stream()), "gdfn_fwd_f8")
+        return out
     # A/B switch: keep the conv output instead of recomputing it in backward.  Read here, once per forward; backward
     # recovers the choice from the blob's size, so toggling the variable between the two cannot desynchronise them.
     s = _gdfn_shape(x, hidden, ks, 1 if os.environ.get("MI_GDFN_STORE_Y") else 0)

@@ -208,19 +208,116 @@ def _fused_gdfn_pack(holder, like: Tensor, ln_params, ffn_params) -> Tensor:
     return cache[1]
 
 
+# ---- fp8 (e4m3) MFMA operands in the 1x1 projections: the tiled-inference configuration (BASELINE configs[4]) -------------------
+# Activations stay bf16 in HBM; a projection's input and weight are divided by a power-of-two scale and rounded to e4m3 in
+# registers on their way into v_mfma_f32_16x16x32_fp8_fp8 (csrc/pw_gemm.hip, PwwOp).  Weight scales come from the weights
+# (max |W|; for MDTA's per-image project_out . softmax product the largest per-head absolute row sum of project_out, which
+# bounds it).  Activation scales are static: ``fp8_calibrate`` runs the bf16 network once over sample tiles, every block records
+# the largest magnitude its two projections saw, and the scale leaves F8_HEADROOM x room above it (e4m3 keeps 3 mantissa bits
+# over ~15 binades, so headroom costs no precision; values past 448 x scale saturate).
+F8_HEADROOM = 4.0
+F8_MAX = 448.0
+F8_COUNTS = {"f8": 0, "bf16": 0}       # projections run in each form since the last reset (coverage report of fp8 mode)
+
+
+def _f8_pow2(bound: float) -> float:
+    import math
+    return 2.0 ** math.ceil(math.log2(max(float(bound), 1e-30) / F8_MAX))
+
+
+def _blocks(model) -> List["TransformerBlock"]:
+    return [m for m in model.modules() if isinstance(m, TransformerBlock)]
+
+
+def fp8_calibrate(model, samples: Sequence[Tensor]) -> None:
+    """Record activation ranges for the fp8 projections: runs ``model`` (bf16, no_grad) over ``samples`` with every
+    TransformerBlock on its unfused path, then stores the four scales of each half-block on the block.  Re-run after the
+    weights change."""
+    blocks = _blocks(model)
+    dev = next(model.parameters()).device
+    for b in blocks:
+        b._f8_cal = torch.zeros(4, dtype=torch.float32, device=dev)     # amax of: norm1 out, v, norm2 out, gated hidden
+    try:
+        with torch.no_grad():
+            for smp in samples:
+                model(smp)
+    finally:
+        cal = [b.__dict__.pop("_f8_cal") for b in blocks]
+    amax = torch.stack(cal).tolist()                                    # one read-back for the whole network
+    for b, a in zip(blocks, amax):
+        wq, wo = b.attn.qkv.weight, b.attn.project_out.weight
+        c = wo.shape[1] // b.attn.num_heads
+        wo_bound = wo.detach().abs().reshape(wo.shape[0], b.attn.num_heads, c).sum(-1).max()
+        wmax = torch.stack([wq.detach().abs().max(), wo_bound, b.ffn.project_in.weight.detach().abs().max(),
+                            b.ffn.project_out.weight.detach().abs().max()]).tolist()
+        b._f8 = {"attn": (_f8_pow2(F8_HEADROOM * a[0]), _f8_pow2(wmax[0]), _f8_pow2(F8_HEADROOM * a[1]), _f8_pow2(wmax[1])),
+                 "ffn": (_f8_pow2(F8_HEADROOM * a[2]), _f8_pow2(wmax[2]), _f8_pow2(F8_HEADROOM * a[3]), _f8_pow2(wmax[3]))}
+
+
+def fp8_projections(model, mode: Optional[str]) -> None:
+    """Switch the no_grad forward of every TransformerBlock: ``"all"`` = all four 1x1 projections on fp8 MFMA operands,
+    ``"attn"`` = qkv and project_out of the attention half only (the feed-forward half stays on the one-launch bf16 kernel
+    where that covers the shape), ``None`` = bf16.  Needs ``fp8_calibrate`` first."""
+    if mode not in (None, "all", "attn"):
+        raise ValueError("fp8_projections: mode is None, 'all' or 'attn'")
+    for b in _blocks(model):
+        if mode is not None and getattr(b, "_f8", None) is None:
+            raise RuntimeError("fp8_projections: run fp8_calibrate(model, samples) first")
+        b._f8_mode = mode
+
+
+def _block_calibrate(block, x: Tensor, params, cal: Tensor) -> Tensor:
+    """The block's bf16 forward, unfused, recording the magnitudes the four projections read."""
+    n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
+    wb = n1[1] is not None
+    Cc = x.shape[1]
+    xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
+    v = ops.dwconv_fwd(ops.conv1x1(xn, att[1][2 * Cc:], None if att[2] is None else att[2][2 * Cc:]),
+                       att[3][2 * Cc:].contiguous(), None if att[4] is None else att[4][2 * Cc:].contiguous())
+    y, _ = ops.mdta_fwd(xn, x, att, block.attn.num_heads, False)
+    yn, _, _ = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=False)
+    g = ops.dwconv_gate_fwd(ops.conv1x1(yn, ffn[0], ffn[1]), ffn[2], ffn[3], want_y=False)[1]
+    out, _ = ops.gdfn_fwd(yn, y, ffn, False)
+    seen = torch.stack([xn.abs().max(), v.abs().max(), yn.abs().max(), g.abs().max()]).float()
+    torch.maximum(cal, seen, out=cal)
+    return out
+
+
 def _block_infer(block, x: Tensor, params) -> Tensor:
     """TransformerBlock.forward under no_grad (Restormer.py:146-150): nothing is saved, and the second half of the block
-    (norm2 -> ffn -> +x) runs as ONE kernel where the fused GDFN covers the shape (bf16, C = 48 / 96, tile-aligned planes)."""
+    (norm2 -> ffn -> +x) runs as ONE kernel where the fused GDFN covers the shape (bf16, C = 48 / 96, tile-aligned planes).
+    With ``fp8_projections`` on, the 1x1 projections take fp8 MFMA operands where the kernel form allows."""
     _gpu_block_input(x)
+    cal = getattr(block, "_f8_cal", None)
+    if cal is not None:
+        return _block_calibrate(block, x, params, cal)
     n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
     wb = n1[1] is not None
     heads = block.attn.num_heads
-    if ops.mdta_fwd_ln_ok(x, heads, att[3].shape[-1]) and not os.environ.get("MI_NO_LN_HEAD"):   # norm1 inside the qkv GEMM
-        y = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], False))[0]
+    mode = getattr(block, "_f8_mode", None) if x.dtype == torch.bfloat16 else None
+    ks_a = att[3].shape[-1]
+    ln_a = ops.mdta_fwd_ln_ok(x, heads, ks_a) and not os.environ.get("MI_NO_LN_HEAD")        # norm1 inside the qkv GEMM
+    f8_a = block._f8["attn"] if mode and ops.mdta_fwd_f8_ok(x, heads, ks_a, bool(ln_a)) else None
+    if mode:
+        F8_COUNTS["f8" if f8_a else "bf16"] += 2
+    if ln_a:
+        y = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], False), f8=f8_a)
+        y = y if f8_a else y[0]
     else:
         xn, _, _ = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=False)
-        y, _ = ops.mdta_fwd(xn, x, att, heads, False)
+        y = ops.mdta_fwd(xn, x, att, heads, False, f8=f8_a)
+        y = y if f8_a else y[0]
     hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
+    if mode == "all":
+        ln_f = ops.gdfn_fwd_ln_ok(y, hidden, ks) and not os.environ.get("MI_NO_LN_HEAD")
+        if ops.gdfn_fwd_f8_ok(y, hidden, ks, bool(ln_f)):
+            F8_COUNTS["f8"] += 2
+            if ln_f:
+                return ops.gdfn_fwd(y, y, ffn, False, ln=(n2[0], n2[1], False), f8=block._f8["ffn"])
+            yn, _, _ = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=False)
+            return ops.gdfn_fwd(yn, y, ffn, False, f8=block._f8["ffn"])
+    if mode:
+        F8_COUNTS["bf16"] += 2
     if ops.gdfn_fused_ok(y, hidden, ks) and not os.environ.get("MI_NO_FUSED_INFER"):      # (A/B switch)
         pack = _fused_gdfn_pack(block, y, n2, ffn)
         out, _, _ = ops.gdfn_fused_fwd(y, pack, hidden, wb, want_stats=False)

@@ -114,10 +114,18 @@ typedef struct {
    * [batch, n] receive the statistics (both or neither).  Only where mi_pw_gemm_ln_ok() says so (the X-resident kernel:
    * bf16, 96 < M, K <= 96, one K panel, one group); zero-initialise the struct to leave it off. */
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;
+  /* Optional fp8 (OCP e4m3) MFMA operands - the "CDNA4 fp8 MFMA projections" of the tiled-inference configuration (BASELINE
+   * configs[4]); inference only.  f8 = 1: X (after the optional LayerNorm) is divided by f8_sx and W (its packed bf16 image)
+   * by f8_sw, both are rounded to e4m3 in registers (saturating at +-448) and multiplied with v_mfma_f32_16x16x32_fp8_fp8; the fp32 accumulator
+   * is scaled back by f8_sx * f8_sw before bias / residual.  The hardware conversion uses the scales' exponents only: pass
+   * powers of two, chosen so that |X| / f8_sx and |W| / f8_sw stay <= 448.  X, Y and the residual stay bf16 in HBM.  Only
+   * where mi_pw_gemm_f8_ok() says so (the wave-owned bf16 kernels); zero-initialise the struct to leave it off. */
+  int f8; float f8_sx, f8_sw;
 } mi_pw_desc;
 size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
 int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
 int mi_pw_gemm_ln_ok(const mi_pw_desc* d);
+int mi_pw_gemm_f8_ok(const mi_pw_desc* d);
 
 /* Opt-in packed-weight cache.  By default every mi_pw_gemm (and every module entry point built on it) packs its weight
  * matrix into its own workspace, once per call, and the library keeps no state.  A caller that controls when the
@@ -276,6 +284,19 @@ int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_
 int mi_gdfn_fwd_ln_ok(const mi_gdfn_shape* s);
 int mi_gdfn_fwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const void* x, const void* residual,
                    void* out, void* saved, void* ws, void* stream);
+/* fp8 (e4m3) MFMA operands in both 1x1 projections of a half-block - inference only (nothing is saved), bf16 activations in
+ * HBM; see mi_pw_desc.f8.  x1 / w1 scale the first projection's input and weight (qkv: Restormer.py:105,114; project_in:
+ * :82,89), x2 / w2 the second's (project_out, :107,131 - for MDTA its input is v and its weight the per-image product
+ * project_out . softmax(..), |entries| <= (C / heads) max|project_out|; :86,92 for GDFN, input gelu(x1) x2).  Powers of two
+ * with |operand| / scale <= 448 (values past that saturate).  ln may be NULL (x is then the LayerNorm output).
+ * Shapes: mi_*_fwd_f8_ok(shape, with_ln). */
+typedef struct { float x1, w1, x2, w2; } mi_f8_scales;
+int mi_mdta_fwd_f8_ok(const mi_mdta_shape* s, int with_ln);
+int mi_mdta_fwd_f8(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const mi_f8_scales* f8, const void* x,
+                   const void* residual, void* out, void* ws, void* stream);
+int mi_gdfn_fwd_f8_ok(const mi_gdfn_shape* s, int with_ln);
+int mi_gdfn_fwd_f8(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const mi_f8_scales* f8, const void* x,
+                   const void* residual, void* out, void* ws, void* stream);
 int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype);
 size_t mi_bwd_tail_workspace(int M, int C);
 int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
