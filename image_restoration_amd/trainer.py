@@ -11,6 +11,7 @@ buffer (``param.main_grad``), so no per-parameter autograd accumulation kernels 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -36,7 +37,10 @@ class FlatTrainer:
         self._host_update = host_update
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if inited else 1
+        # MI_FORCE_COMM=1: run every collective even in a one-rank group (rehearsal of the RCCL code path on a one-GPU box)
+        self._comm = self.world > 1 or (inited and os.environ.get("MI_FORCE_COMM") == "1")
         self.step_count = 0
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "model has no trainable parameters"
@@ -47,8 +51,8 @@ class FlatTrainer:
         for p in params:
             offs.append(total)
             total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        self.sharded = bool(shard_optimizer) and self.world > 1
-        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.sharded = bool(shard_optimizer) and self._comm
+        self.rank = dist.get_rank(process_group) if self._comm else 0
         if self.sharded:                                   # equal, aligned shards: pad the flat buffers at the end
             self.shard = (total + self.world * ALIGN - 1) // (self.world * ALIGN) * ALIGN
             total = self.shard * self.world
@@ -86,11 +90,11 @@ class FlatTrainer:
                 hi = max(self.offsets[id(p)][0] + (self.offsets[id(p)][1] + ALIGN - 1) // ALIGN * ALIGN for p in ps)
                 self.stages.append((uname, unit, lo, hi))
         self._param_lists: dict = {}
-        self.overlap = overlap and self.world > 1 and not self.sharded
+        self.overlap = overlap and self._comm and not self.sharded
         self._exec_order: List[int] = []
         self._reduced: set = set()
         self._works = []
-        self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.world > 1) else None
+        self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self._comm) else None
         if self.overlap:
             for idx, (_, child, _, _) in enumerate(self.stages):
                 child.register_forward_hook(self._make_fwd_hook(idx))
@@ -234,7 +238,7 @@ class FlatTrainer:
             self._next -= 1
 
     def _launch_reduce(self, idx: int) -> None:
-        if idx in self._reduced or self.world == 1:
+        if idx in self._reduced or not self._comm:
             return
         self._reduced.add(idx)
         _, child, lo, hi = self.stages[idx]
@@ -249,7 +253,7 @@ class FlatTrainer:
 
     def reduce_gradients(self) -> None:
         """Call after backward: folds autograd-delivered grads, all-reduces whatever is not yet in flight, waits."""
-        if self.world == 1:
+        if not self._comm:
             self._fold_autograd_grads(self.model)
             return
         if self.sharded:
