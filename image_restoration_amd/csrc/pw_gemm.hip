@@ -108,6 +108,7 @@ struct PwG {
   int wp_per_batch, wp_per_group, k_chunks;
   // LayerNorm of X applied on the way in (xres form only): gamma / beta [K], statistics out [batch][n] (or null)
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;   // 0 none, 1 WithBias, 2 BiasFree
+  int xcd_map;              // stream form: XCD-aware workgroup order (see the kernel)
   float f8_sx, f8_sw;       // fp8 operand forms: X / f8_sx and W / f8_sw are rounded to e4m3, the accumulator is scaled by their product
 };
 
@@ -897,11 +898,25 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   const int t = threadIdx.x, lane = t & 63, li = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: the wave's patch, tile range and their addresses stay out of the VGPRs
   bf16* const patch = Wl + (int64_t)nchunks * TM * WS_ROW + wv * PWW_PATCH;
-  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  // Wide outputs: one workgroup per 16 MF-channel tile, and every tile streams the workgroup's X range again.  Workgroups are
+  // handed to the 8 XCDs round-robin in launch order, so with the plain (x, y, z) order the m-tiles of one X range land on
+  // different L2s.  xcd_map: XCD j instead takes the j-th contiguous eighth of the list ordered (image, pixel range, m-tile)
+  // with the m-tile fastest - all m-tiles of an X range run back to back on ONE L2 and only the first of them goes to HBM.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (q.xcd_map) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned per = gridDim.x * gridDim.y * gridDim.z / 8u;
+    const unsigned w = lin / 8u + per * (lin % 8u);
+    by = (int)(w % gridDim.y);
+    const unsigned u = w / gridDim.y;
+    bx = (int)(u % gridDim.x);
+    bz = (int)(u / gridDim.x);
+  }
+  const int z = bz, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
-  const int m0 = blockIdx.y * TM;                                    // wide outputs: one workgroup per 16 MF-channel tile (X is re-read per tile)
+  const int m0 = by * TM;
   pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
-                            (int64_t)blockIdx.y * nchunks * chunk_stride_elems, nchunks, TM, chunk_stride_elems, t);
+                            (int64_t)by * nchunks * chunk_stride_elems, nchunks, TM, chunk_stride_elems, t);
   __syncthreads();
   PwwX x;
   x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
@@ -913,7 +928,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
   o.m = p.m; o.n = p.n;
   const int64_t n_tiles = p.n / PW_TN;
-  const int64_t tile0 = ((int64_t)blockIdx.x * PWW_MW + wv) * tiles_per_wave;
+  const int64_t tile0 = ((int64_t)bx * PWW_MW + wv) * tiles_per_wave;
   const bf16* wl = Wl + li * WS_ROW + 4 * g;
   for (int tt = 0; tt < tiles_per_wave; ++tt) {
     const int64_t tile = tile0 + tt;
@@ -986,6 +1001,141 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   }
 }
 
+// ---- X-resident, W streamed (wave form 3): the wide projections of the C = 128 .. 192 levels --------------------------------------
+// The streaming form above re-reads X once per 96-channel tile, and its waves use each 4 KB X chunk for 24 MFMAs only: at K = 192,
+// M = 576 / 1020 that is ~50 TB/s of L2 traffic at full MFMA rate, and the kernel sits at 15-20 % of the MFMA peak on L2 bandwidth
+// (an XCD-aware tile order did not move it: profiles/r02_i_pw_xcd_map_ab.txt).  Here a wave keeps the MFMA fragments of its 64
+// pixels for ALL of K in registers (KB x 16 VGPRs) and the workgroup walks the output channels 64 at a time: the weight image of
+// one 64-row tile (KB chunk images, 30 KB at K = 192) is staged into LDS by all eight waves - double-buffered, the next tile's
+// loads in flight during this tile's MFMAs, one barrier per tile - and every wave multiplies it with its resident X.  X is read
+// once; the weights come from L2 once per workgroup.  Measured at bs 32 (profiles/r02_j_pw_xwide_deep_shapes.txt): 576 x 192 75 -> 59 us,
+// 1020 x 192 141 -> 105 us, 510 x 192 (W^T) 74 -> 53 us - now bound by the output writes (3.0-3.4 TB/s of the 4.45 TB/s write roof).
+// A 32-pixel-per-wave variant for K = 193 .. 384 (fragments still 96 VGPRs) was built, parity-tested and measured: no gain at the latent
+// level (1152 x 384 66 -> 71 us, 2042 x 384 122 -> 112 us) - each weight fragment read from LDS then feeds only 2 MFMAs - and was dropped.
+template <int KB, bool F8>
+__global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, int n_slabs, int slabs_per_wg, int chunk_stride_elems) {
+  using Op = PwwOp<F8>;
+  Op::enter();
+  const PwK& p = q.k;
+  constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 64;
+  constexpr int NF = 4, SR = 64, TNW = PW_TN;                        // pixel fragments per wave, channels per staged slab, pixels per wave
+  constexpr int VPC = SR * WS_ROW / 8;                               // 16-byte vectors per chunk image inside one slab
+  constexpr int VPS = KB * VPC;
+  constexpr int NT = 64 * PWW_MW;
+  constexpr int VPT = (VPS + NT - 1) / NT;
+  constexpr int SLAB = KB * SR * WS_ROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  bf16* const Wl = reinterpret_cast<bf16*>(lds_dyn);                 // [2][KB][SR][WS_ROW]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  bf16* const patch = Wl + 2 * SLAB + wv * PWW_PATCH;
+  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
+  const bf16* const wpk = reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice;
+  const int s0 = blockIdx.y * slabs_per_wg;
+  const int s1 = s0 + slabs_per_wg < n_slabs ? s0 + slabs_per_wg : n_slabs;
+  u32x4 wr[VPT];
+  auto w_load = [&](int sl) {                                        // slab sl = rows [SR sl, SR sl + SR) of the packed 64-row tiles
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const int mt = sl * SR / TM, r0 = sl * SR - mt * TM;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tt + NT * i;
+      if (v < VPS) {
+        const int c = v / VPC, o = v - c * VPC;
+        wr[i] = reinterpret_cast<const u32x4*>(wpk + ((int64_t)mt * KB + c) * chunk_stride_elems + r0 * WS_ROW)[o];
+      }
+    }
+  };
+  auto w_store = [&](int buf) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tt + NT * i;
+      if (v < VPS) reinterpret_cast<u32x4*>(Wl + buf * SLAB)[v] = wr[i];
+    }
+  };
+  w_load(s0);
+
+  PwwX x;
+  x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
+  x.x2 = p.x2 ? (const bf16*)p.x2 + zb * p.x2_bs + zg * p.x2_gs : x.x1;
+  x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
+  PwwOut o;
+  o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
+  o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
+  o.m = p.m; o.n = p.n;
+  const int64_t tile = (int64_t)blockIdx.x * PWW_MW + wv;
+  const bool valid = tile < p.n / TNW;                               // (waves past the plane still stage weights and meet the barriers)
+  const int64_t n0 = tile * TNW;
+  typename Op::Frag a[KB][NF];
+  if (valid) {
+    u32x4 raw[KB][NF];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      pww_load_chunk(raw[kb], x, kb, n0, lane);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      s16x8 a16[NF];
+      pww_chunk_to_frags(a16, raw[kb], patch, kb, x.ktot, lane);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) a[kb][nf] = Op::cvt(a16[nf], q.f8_sx);
+    }
+  }
+  w_store(0);
+  __syncthreads();
+  for (int sl = s0; sl < s1; ++sl) {
+    const int buf = (sl - s0) & 1;
+    if (sl + 1 < s1) w_load(sl + 1);
+    if (valid) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int li_ = ln & 15, g_ = ln >> 4;
+#pragma unroll 1
+      for (int h = 0; h < SR / 32; ++h) {                            // 32 output channels per trip
+        const int mbase = sl * SR + 32 * h;
+        if (mbase >= p.m) break;
+        const bf16* wt = Wl + buf * SLAB + (32 * h + li_) * WS_ROW + 4 * g_;
+        f32x4 acc[2][NF];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[f][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const typename Op::Frag b = Op::cvt(pww_w_frag(wt + (kb * SR + 16 * f) * WS_ROW), q.f8_sw);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[f][nf] = Op::mma(a[kb][nf], b, acc[f][nf]);
+          }
+        if (F8) {
+          const float os = q.f8_sx * q.f8_sw;
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[f][nf] *= os;
+        }
+        if (!o.r) {
+          pww_store_bf16<2>(acc[0], acc[1], patch, o, mbase, n0, ln);
+        } else {
+          u32x4 rr[2];
+          pww_load_res(rr, o, mbase, n0, ln);
+          pww_store_frag(acc[0], rr, reinterpret_cast<float*>(patch), o, mbase, n0, ln);
+          pww_load_res(rr, o, mbase + 16, n0, ln);
+          pww_store_frag(acc[1], rr, reinterpret_cast<float*>(patch), o, mbase + 16, n0, ln);
+        }
+      }
+    }
+    if (sl + 1 < s1) w_store(buf ^ 1);
+    __syncthreads();
+  }
+}
+
 struct PwPlan { int tm, m_tiles, k_chunks, slices, per_batch, per_group, chunk_elems, wave; int64_t slice_elems; size_t bytes; };
 constexpr size_t PWW_LDS_MAX = 160 * 1024;
 
@@ -1028,8 +1178,11 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
     const bool off = (e && e[0] == '0') || getenv("MI_PW_DMA") || getenv("MI_PW_CHUNKED");
     if (allow_wave && !off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
       const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
+      const char* xw = getenv("MI_PW_XWIDE");                          // A/B switch
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches + 768 <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
+      } else if (d->m >= 256 && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {
+        pl.wave = 3; pl.tm = 64;                                       // X-resident, W streamed (K = 97 .. 192, wide outputs)
       } else {
         // stream: one 96- / 64- / 48-channel tile per workgroup; wide outputs tile M (every tile streams X again, like the
         // chunked kernel), preferring the tile height that moves the fewest rows and fits beside the patches
@@ -1135,6 +1288,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   q.wp_per_group = pl.per_group; q.k_chunks = pl.k_chunks;
   q.ln_w = d->ln_w; q.ln_b = d->ln_b; q.ln_mean = d->ln_mean; q.ln_rstd = d->ln_rstd; q.ln_mode = d->ln_mode;
   q.f8_sx = d->f8_sx; q.f8_sw = d->f8_sw;
+  q.xcd_map = 0;
   if (d->f8) {
     MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: fp8 operands need a wave-owned bf16 form (mi_pw_gemm_f8_ok)");
     MI_CHECK_ARG(d->f8_sx > 0.f && d->f8_sw > 0.f, "pw_gemm: fp8 operand scales must be positive (powers of two)");
@@ -1170,13 +1324,38 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
       if (tpw < 1) tpw = 1;
       if (tpw > 8) tpw = 8;
       dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), pl.wave == 2 ? pl.m_tiles : 1, grid.z), wblock(64 * PWW_MW);
-      const size_t lds = wbytes + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
+      size_t lds = wbytes + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
+      int n_slabs = 0, slabs_per = 0;
+      if (pl.wave == 3) {                                              // one 64-pixel tile per wave; M split only to fill the chip
+        const int sr = 64;
+        wgrid.x = (unsigned)cdiv(n_tiles, PWW_MW);
+        n_slabs = cdiv(d->m, sr);
+        const int64_t wgs = (int64_t)wgrid.x * grid.z;
+        const int64_t split = wgs >= 200 ? 1 : std::min<int64_t>(n_slabs, cdiv(256, wgs));
+        slabs_per = (int)cdiv(n_slabs, split);
+        wgrid.y = (unsigned)cdiv(n_slabs, slabs_per);
+        lds = (size_t)2 * pl.k_chunks * sr * row + patches;
+      }
+      {
+        const char* e = getenv("MI_PW_XCD");                           // A/B switch
+        const int min_tiles = e ? atoi(e) : 0;   // off by default: measured no gain (profiles/r02_i_pw_xcd_map_ab.txt)
+        const uint64_t total = (uint64_t)wgrid.x * wgrid.y * wgrid.z;
+        q.xcd_map = (pl.wave == 2 && min_tiles > 0 && (int)wgrid.y >= min_tiles && total % 8 == 0 && total < (1ull << 31)) ? 1 : 0;
+      }
 #define PWW_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                       \
     if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(KERNEL, wgrid, wblock, lds, st, q, __VA_ARGS__);                                                      \
   } while (0)
-      if (pl.wave == 1 && !d->f8) {
+      if (pl.wave == 3) {
+#define PWX_CASE(KB_)                                                                                                          \
+  if (pl.k_chunks == KB_) {                                                                                                    \
+    if (d->f8) PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, true>), n_slabs, slabs_per, pl.chunk_elems);                         \
+    else PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, false>), n_slabs, slabs_per, pl.chunk_elems);                              \
+  }
+        PWX_CASE(4) else PWX_CASE(5) else PWX_CASE(6)
+#undef PWX_CASE
+      } else if (pl.wave == 1 && !d->f8) {
         if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
         else if (pl.k_chunks == 2) PWW_LAUNCH((pw_gemm_wave_xres_kernel<2, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
         else PWW_LAUNCH((pw_gemm_wave_xres_kernel<3, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);

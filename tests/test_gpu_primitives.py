@@ -373,3 +373,40 @@ def test_pw_wave_forms_fuzz_against_chunked(monkeypatch):
             y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), None if bias is None else bias.to(DEV),
                         None if res is None else res.to(DEV), M, groups, per_image, transposed)
             assert torch.equal(y.float().cpu(), ref), (case, wave, M, K1, K2, groups, per_image, transposed, hw, use_bias, use_res)
+
+
+@pytest.mark.parametrize("epilogue", ["none", "bias", "res", "bias+res"])
+@pytest.mark.parametrize("M,K1,K2,per_image,transposed,hw", [
+    (576, 192, 0, False, False, (16, 64)), (1020, 192, 0, False, False, (8, 72)), (300, 130, 0, False, True, (3, 64)),
+    (256, 128, 0, True, False, (8, 72)), (600, 97, 0, False, False, (1, 64)), (510, 100, 92, False, True, (16, 64)),
+    (2042, 160, 0, False, False, (4, 64)),
+    # K > 192 stays on the streaming form: same expectations
+    (1152, 384, 0, False, False, (16, 64)), (300, 200, 0, True, True, (3, 64))])
+def test_pw_xwide_form_exact_on_integers(monkeypatch, epilogue, M, K1, K2, per_image, transposed, hw):
+    """The X-resident / W-streamed wave form (bf16, K = 97 .. 192, M >= 256: the C = 192 level's qkv and project_in): every
+    output-channel tile walked behind one barrier, ragged M inside the last 64-row tile, K tails inside a 32-k chunk, two K
+    panels, per-image weights, waves past the plane (9 tiles on 8-wave workgroups), the M split that fills the chip on small
+    batches.  Integer data -> exact against the host; MI_PW_XWIDE=0 (the streaming form it replaces) must give the same bits."""
+    B, dtype = 2, torch.bfloat16
+    K = K1 + K2
+    x1 = ints((B, K1, *hw), 291).to(dtype)
+    x2 = ints((B, K2, *hw), 292).to(dtype) if K2 else None
+    w = ints((B if per_image else 1, 1, M, K), 293, -2, 3)
+    bias = ints((1, M), 294) if "bias" in epilogue else None
+    res = ints((B, M, *hw), 295).to(dtype) if "res" in epilogue else None
+    xs = x1.float().reshape(B, 1, K1, -1)
+    if K2:
+        xs = torch.cat([xs, x2.float().reshape(B, 1, K2, -1)], 2)
+    ref = torch.einsum("bgmk,bgkn->bgmn", w.expand(B, -1, -1, -1), xs)
+    if bias is not None:
+        ref = ref + bias[None, :, :, None]
+    ref = ref.reshape(B, M, *hw)
+    if res is not None:
+        ref = ref + res.float()
+    ref = ref.to(dtype).float()
+    warg = w.transpose(-1, -2).contiguous() if transposed else w
+    for xwide in ("1", "0"):
+        monkeypatch.setenv("MI_PW_XWIDE", xwide)
+        y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), None if bias is None else bias.to(DEV),
+                    None if res is None else res.to(DEV), M, 1, per_image, transposed)
+        assert torch.equal(y.float().cpu(), ref), (xwide, float((y.float().cpu() - ref).abs().max()))

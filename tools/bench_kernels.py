@@ -35,6 +35,13 @@ def bench_pw():
         (288, 96, 128, 128, False, False), (510, 96, 128, 128, False, False), (96, 255, 128, 128, False, True),
         (576, 192, 64, 64, False, False), (1020, 192, 64, 64, False, False), (1152, 384, 32, 32, False, False),
     ]
+    if os.environ.get("BK_DEEP"):      # the C >= 192 levels only (forward, input-gradient and attention-product shapes)
+        shapes = [(576, 192, 64, 64, False, False), (1020, 192, 64, 64, False, False), (192, 510, 64, 64, False, True),
+                  (192, 192, 64, 64, False, True), (192, 576, 64, 64, True, False), (192, 1020, 64, 64, True, False),
+                  (510, 192, 64, 64, True, False),
+                  (1152, 384, 32, 32, False, False), (2042, 384, 32, 32, False, False), (384, 1021, 32, 32, False, True),
+                  (384, 384, 32, 32, False, True), (384, 1152, 32, 32, True, False), (384, 2042, 32, 32, True, False),
+                  (1021, 384, 32, 32, True, False)]
     for (M, K, H, W, tr, res) in shapes:
         x = torch.randn(B, K, H, W, device="cuda").bfloat16()
         w = torch.randn((K, M) if tr else (M, K), device="cuda")
