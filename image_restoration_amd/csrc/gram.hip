@@ -20,6 +20,7 @@ struct GramK {
   float* part;     // [splits][Z][ma][mb]
   float* ss_part;  // [splits][Z][ma+mb] or null
   int chunks_per_split, nchunks, tiles_b, vec_ok;
+  int fold;        // > 0: the batch is folded into the pixel axis (weight gradients): chunk / step c lies in image c / fold
 };
 
 template <typename T, int F, bool SS>
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar wave index)
   const int li = lane & 15, g = lane >> 4;
   const int wr = wv >> 1, wc = wv & 1;
-  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int z = blockIdx.z, zb = p.fold ? 0 : z / p.groups, zg = p.fold ? z : z - zb * p.groups;
   const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
   const int i0 = ta * TA, j0 = tb * TA;
   const T* A = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
@@ -47,9 +48,14 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   u32x4 areg[F], breg[F];
   // (thread / lane ids below are opaque copies: the per-lane address terms are loop-invariant, and kept across the chunk loop
   //  they are what lifts this kernel over the 170 registers that allow a third workgroup per CU)
-  auto load_rows = [&](const T* base, int row0, int rows, int chunk, u32x4* regs) {
+  auto load_rows = [&](const T* base, int64_t img_stride, int row0, int rows, int chunk, u32x4* regs) {
     int tt = t;
     asm volatile("" : "+v"(tt));
+    if (p.fold) {                                                    // (uniform) image of this chunk, chunk inside the image
+      const int img = chunk / p.fold;
+      base += img * img_stride;
+      chunk -= img * p.fold;
+    }
 #pragma unroll
     for (int i = 0; i < F; ++i) {
       const int v = tt + 256 * i;
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   const int ra = wr * 16 * F, cb = wc * 16 * F;  // wave's first row / col inside the tile
 
   if (c_begin < c_end) {
-    load_rows(A, i0, p.ma, c_begin, areg);
-    load_rows(B, j0, p.mb, c_begin, breg);
+    load_rows(A, p.a_bs, i0, p.ma, c_begin, areg);
+    load_rows(B, p.b_bs, j0, p.mb, c_begin, breg);
   }
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();
@@ -103,8 +109,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
     write_rows(Bs, breg);
     __syncthreads();
     if (c + 1 < c_end) {
-      load_rows(A, i0, p.ma, c + 1, areg);
-      load_rows(B, j0, p.mb, c + 1, breg);
+      load_rows(A, p.a_bs, i0, p.ma, c + 1, areg);
+      load_rows(B, p.b_bs, j0, p.mb, c + 1, breg);
     }
     if constexpr (F32) {
 #pragma unroll
@@ -196,11 +202,11 @@ __global__ __launch_bounds__(256) void gram_stream_kernel(GramK p, int steps_per
   __shared__ float ssm[SS ? 4 : 1][SS ? (FA + FB) * 16 : 1];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar wave index)
   const int li = lane & 15, g = lane >> 4;
-  const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
+  const int z = blockIdx.z, zb = p.fold ? 0 : z / p.groups, zg = p.fold ? z : z - zb * p.groups;
   const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
   const int i0 = ta * 16 * FA, j0 = tb * 16 * FB;
-  const T* A = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
-  const T* B = (const T*)p.b + zb * p.b_bs + zg * p.b_gs;
+  const T* A0 = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
+  const T* B0 = (const T*)p.b + zb * p.b_bs + zg * p.b_gs;
   const int s_begin = blockIdx.x * steps_per_block;
   const int s_end = min(s_begin + steps_per_block, nsteps);
 
@@ -212,7 +218,15 @@ __global__ __launch_bounds__(256) void gram_stream_kernel(GramK p, int steps_per
     asm volatile("" : "+v"(ln));
     const int li_ = ln & 15, g_ = ln >> 4;
     // 32-bit element offsets from the (uniform) operand bases: one slice is at most rows * n < 2^31 elements (gram_stream_ok)
-    const unsigned px = (unsigned)s * 64u + 8u * g_;     // this lane's first pixel of k-step 0; k-step 1 is 32 further
+    const T* A = A0;
+    const T* B = B0;
+    int sl = s;                                          // step inside its image
+    if (p.fold) {
+      const int img = s / p.fold;
+      sl = s - img * p.fold;
+      A += img * p.a_bs; B += img * p.b_bs;
+    }
+    const unsigned px = (unsigned)sl * 64u + 8u * g_;    // this lane's first pixel of k-step 0; k-step 1 is 32 further
     const unsigned un = (unsigned)p.n;
     const bool in0 = s < s_end && px + 8 <= un, in1 = s < s_end && px + 40 <= un;
 #pragma unroll
@@ -386,7 +400,28 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
-struct GramPlan { int F, kc, nchunks, tiles_a, tiles_b, splits, cps, Z; size_t part_bytes, ss_bytes; };
+struct GramPlan { int F, kc, nchunks, tiles_a, tiles_b, splits, cps, Z, fold; size_t part_bytes, ss_bytes; };
+
+// Weight gradients sum over the batch: instead of one partial tile per image (and a reduction over batch x splits partials),
+// the images are chained along the contraction axis - a workgroup's pixel range may cross image boundaries - whenever an image
+// is a whole number of chunks / steps.  Returns the chunks per image, or 0.  Measured at bs 32 (profiles/r02_k_gram_fold_ab.txt):
+// it pays where an image is short (32 x 32 planes: 16 chunks per workgroup against a 64 KB partial tile each - 1152 x 384
+// 102 -> 76 us, 2042 x 384 144 -> 127 us) and where images x tiles leaves the chip half empty (576 x 192 at 64 x 64: 320
+// workgroups, 163 -> 125 us); on long planes the per-chunk image lookup costs 5-10 % and buys nothing, so those stay per image.
+static int gram_fold(const mi_gram_desc* d, int unit, int64_t tiles_per_image) {
+  const char* e = getenv("MI_GRAM_FOLD");                            // A/B switch: 0 never, 2 wherever possible
+  if (e && e[0] == '0') return 0;
+  if (!d->sum_batch || d->batch <= 1 || d->sumsq || d->n % unit != 0 || d->n / unit > (1 << 20)) return 0;
+  // (second case: the per-image plan would run ONE split - 512 / workgroups rounds to 1 - on a chip it does not fill)
+  const int64_t wgs = tiles_per_image * d->batch;
+  const bool pays = d->n / unit <= 16 || (wgs > 256 && wgs < 448);
+  if (!pays && !(e && e[0] == '2')) return 0;
+  return (int)(d->n / unit);
+}
+static int gram_want(int dflt) {
+  const char* e = getenv("MI_GRAM_WANT");                            // A/B switch: workgroups the pixel split aims for
+  return e ? atoi(e) : dflt;
+}
 
 static GramPlan gram_plan(const mi_gram_desc* d) {
   GramPlan g;
@@ -396,9 +431,11 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
   g.nchunks = cdiv(d->n, g.kc);
   g.tiles_a = cdiv(d->ma, tile);
   g.tiles_b = cdiv(d->mb, tile);
-  g.Z = d->batch * d->groups;
+  g.fold = gram_fold(d, g.kc, (int64_t)g.tiles_a * g.tiles_b * d->groups);
+  if (g.fold) g.nchunks = d->batch * g.fold;
+  g.Z = (g.fold ? 1 : d->batch) * d->groups;
   const int64_t tiles = (int64_t)g.tiles_a * g.tiles_b * g.Z;
-  int64_t want = 512 / (tiles > 0 ? tiles : 1);
+  int64_t want = gram_want(512) / (tiles > 0 ? tiles : 1);
   if (want < 1) want = 1;
   if (want > g.nchunks) want = g.nchunks;
   g.cps = cdiv(g.nchunks, want);
@@ -409,7 +446,7 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
 }
 
 // streaming plan (bf16, 16-byte aligned rows): fragment counts per tile and the pixel split
-struct GramSPlan { int fa, fb, tiles_a, tiles_b, nsteps, spb, splits, Z; size_t part_bytes, ss_bytes; };
+struct GramSPlan { int fa, fb, tiles_a, tiles_b, nsteps, spb, splits, Z, fold; size_t part_bytes, ss_bytes; };
 static int gram_pick_frags(int m) {
   int best = 3, best_pad = 1 << 30;
   for (int f : {3, 4, 6}) {
@@ -425,10 +462,11 @@ static GramSPlan gram_splan(const mi_gram_desc* d) {
   if (g.fa * g.fb > 24) { if (g.fa >= g.fb) g.fa = 3; else g.fb = 3; }  // 6x6 -> 3x6: accumulators + two stages of loads <= 256 VGPRs
   g.tiles_a = cdiv(d->ma, 16 * g.fa);
   g.tiles_b = cdiv(d->mb, 16 * g.fb);
-  g.Z = d->batch * d->groups;
-  g.nsteps = (int)cdiv(d->n, 64);
+  g.fold = gram_fold(d, 64, 0);                                     // (streaming form: short planes only)
+  g.Z = (g.fold ? 1 : d->batch) * d->groups;
+  g.nsteps = g.fold ? d->batch * g.fold : (int)cdiv(d->n, 64);
   const int64_t tiles = (int64_t)g.tiles_a * g.tiles_b * g.Z;
-  int64_t want = 768 / (tiles > 0 ? tiles : 1);
+  int64_t want = gram_want(768) / (tiles > 0 ? tiles : 1);
   const int64_t cap = g.nsteps / 32 > 0 ? g.nsteps / 32 : 1;   // >= 8 steps per wave: the prefetch pipeline needs a run
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -455,7 +493,7 @@ static bool gram_stream_ok(const mi_gram_desc* d) {
   // re-reads and 1-wave occupancy lose to the LDS-staged 128x128 tiles (0.6-0.85x).
   const GramSPlan g = gram_splan(d);
   if (getenv("MI_GRAM_STREAM_ALL")) return true;   // A/B switch
-  if (d->n < 4096) return false;
+  if ((g.fold ? (int64_t)d->batch * d->n : d->n) < 4096) return false;
   if (g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4) return true;
   // ... and where the 128 x 128 LDS tiles would be mostly padding (288 x 96 fills 56% of 3 x 1 tiles: streaming 1.27x
   // faster at bs 32; 96 x 255 and 510 x 96 fill 75% and stay on the LDS kernel; profiles/r01_y_gram_bs32.log)
@@ -481,7 +519,7 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   GramK k;
   k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
   k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
-  k.n = d->n; k.groups = d->groups; k.Z = g.Z;
+  k.n = d->n; k.groups = d->groups; k.Z = g.Z; k.fold = g.fold;
   const bool direct = gram_direct(d, g.splits);
   k.part = direct ? d->out : (float*)ws;
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
@@ -490,8 +528,9 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   MI_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gram: grid too large");
   const bool ss = d->sumsq != nullptr;
   {
-    ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * 2.0 + 4.0 * g.splits * g.Z * d->ma * d->mb,
-                 2.0 * d->ma * d->mb * (double)d->n * g.Z);
+    const double ZZ = (double)d->batch * d->groups;
+    ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * ZZ * 2.0 + 4.0 * g.splits * g.Z * d->ma * d->mb,
+                 2.0 * d->ma * d->mb * (double)d->n * ZZ);
 #define GS_CASE(FA_, FB_)                                                                                           \
   if (g.fa == FA_ && g.fb == FB_) {                                                                                 \
     if (ss) hipLaunchKernelGGL((gram_stream_kernel<FA_, FB_, true>), grid, block, 0, st, k, g.spb, g.nsteps);       \
@@ -506,8 +545,8 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
-                       d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits,
+                       g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
     MI_LAUNCH_CHECK();
   }
   if (ss) {
@@ -535,7 +574,7 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   GramK k;
   k.a = d->a; k.a_bs = d->a_bs; k.a_gs = d->a_gs; k.ma = d->ma;
   k.b = d->b; k.b_bs = d->b_bs; k.b_gs = d->b_gs; k.mb = d->mb;
-  k.n = d->n; k.groups = d->groups; k.Z = g.Z;
+  k.n = d->n; k.groups = d->groups; k.Z = g.Z; k.fold = g.fold;
   const bool direct = gram_direct(d, g.splits);
   k.part = direct ? d->out : (float*)ws;
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
@@ -549,8 +588,9 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   const bool ss = d->sumsq != nullptr;
   const double es = d->dtype == MI_BF16 ? 2.0 : 4.0;
   {
-  ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * g.Z * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
-               2.0 * d->ma * d->mb * (double)d->n * g.Z);
+  const double ZZ = (double)d->batch * d->groups;
+  ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * ZZ * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
+               2.0 * d->ma * d->mb * (double)d->n * ZZ);
 #define GRAM_CASE(T, F)                                                                     \
   do {                                                                                      \
     if (ss) hipLaunchKernelGGL((gram_kernel<T, F, true>), grid, block, 0, st, k);           \
@@ -565,8 +605,8 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits, d->batch,
-                       d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits,
+                       g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
     MI_LAUNCH_CHECK();
   }
   if (ss) {

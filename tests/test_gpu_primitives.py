@@ -214,6 +214,30 @@ def test_gram_long_reduction_random(dtype):
     assert rel(out, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("ma,mb,B,hw", [(48, 48, 4, (16, 64)), (144, 48, 5, (16, 64)), (576, 192, 3, (16, 64)), (300, 200, 2, (8, 64)),
+                                        (96, 255, 32, (4, 64)), (130, 70, 3, (24, 64))])
+def test_gram_batch_fold_exact_on_integers(monkeypatch, dtype, ma, mb, B, hw):
+    """Weight-gradient Grams (sum over the batch) with the images chained along the contraction axis: workgroup pixel ranges that
+    cross image boundaries, both kernels (LDS-staged and streaming), against the per-image form and the host.  MI_GRAM_FOLD: 0 =
+    never, unset = where the planner finds it pays (short planes / half-empty chip), 2 = wherever an image is whole chunks."""
+    o = ops()
+    a = ints((B, ma, *hw), 151, -2, 3).to(dtype)
+    b = ints((B, mb, *hw), 152, -2, 3).to(dtype)
+    ref = torch.einsum("bin,bjn->ij", a.float().flatten(2), b.float().flatten(2))[None]
+    for mode in ("0", None, "2"):
+        if mode is None:
+            monkeypatch.delenv("MI_GRAM_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("MI_GRAM_FOLD", mode)
+        out = o.gram(a.to(DEV), b.to(DEV), 1, True)
+        assert torch.equal(out.cpu(), ref), (mode, float((out.cpu() - ref).abs().max()))
+        monkeypatch.setenv("MI_GRAM_STREAM_ALL", "1")
+        out = o.gram(a.to(DEV), b.to(DEV), 1, True)
+        monkeypatch.delenv("MI_GRAM_STREAM_ALL")
+        assert torch.equal(out.cpu(), ref), ("stream", mode)
+
+
 # --------------------------------------------------------------------------- AdamW / L1
 def test_adamw_matches_torch():
     o = ops()

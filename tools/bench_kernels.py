@@ -94,8 +94,15 @@ def bench_gram():
     for (ma, mb, H, W, g, sb) in [(48, 48, 256, 256, 1, False), (96, 96, 256, 256, 1, False), (144, 48, 256, 256, 1, True),
                                   (254, 48, 256, 256, 1, True), (510, 96, 256, 256, 1, True), (48, 127, 256, 256, 1, True),
                                   (48, 48, 128, 128, 2, False), (1020, 192, 64, 64, 1, True),
-                                  (288, 96, 256, 256, 1, True), (96, 255, 256, 256, 1, True), (288, 96, 128, 128, 1, True)]:
+                                  (288, 96, 256, 256, 1, True), (96, 255, 256, 256, 1, True), (288, 96, 128, 128, 1, True),
+                                  (96, 255, 128, 128, 1, True), (96, 96, 128, 128, 1, True),
+                                  # the C >= 192 levels' weight gradients (every one of them sums over the batch)
+                                  (576, 192, 64, 64, 1, True), (192, 510, 64, 64, 1, True), (192, 192, 64, 64, 1, True),
+                                  (1152, 384, 32, 32, 1, True), (2042, 384, 32, 32, 1, True), (384, 1021, 32, 32, 1, True),
+                                  (384, 384, 32, 32, 1, True), (1728, 384, 32, 32, 1, True), (864, 192, 64, 64, 1, True)]:
         B = int(os.environ.get("BK_BATCH", "8"))   # 32: operands exceed the 256 MB Infinity Cache, like in the real step
+        if os.environ.get("BK_DEEP") and H > 64:
+            continue
         a = torch.randn(B, ma * g, H, W, device="cuda").bfloat16()
         b = torch.randn(B, mb * g, H, W, device="cuda").bfloat16()
         us = timeit(lambda: ops.gram(a, b, g, sb))
