@@ -18,6 +18,36 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// MFMA operand policy of the bf16 kernels that can also run on fp8 operands (pw_gemm wave forms, fused GDFN).
+// bf16: fragments go to v_mfma_f32_16x16x32_bf16 as they are.  fp8 (mi_pw_desc.f8, mi_gdfn_fused_fwd_f8):
+// the SAME fragments (8 bf16 along k per lane) are divided by a power-of-two scale and rounded to OCP e4m3 in registers - four
+// v_cvt_scalef32_pk_fp8_bf16 per fragment, element e to byte e for A and B alike, so the k-slot order carries over - and go to
+// v_mfma_f32_16x16x32_fp8_fp8.  X is converted once per tile, W once per use (it stays bf16 in LDS).  The conversion returns NaN
+// past +-448 unless MODE.FP16_OVFL is set (measured: tools/microbench/f8_probe.hip): the fp8 kernels set it, so a scale that is
+// too small saturates instead of poisoning the image.
+template <bool F8> struct MfmaOp;
+template <> struct MfmaOp<false> {
+  using Frag = s16x8;
+  static __device__ __forceinline__ void enter() {}
+  static __device__ __forceinline__ Frag cvt(const s16x8 v, float) { return v; }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MfmaOp<true> {
+  using Frag = long;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }   // MODE.FP16_OVFL = 1
+  static __device__ __forceinline__ Frag cvt(const s16x8 v, float scale) {
+    s16x2_t lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[0], v[1]}), scale, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[2], v[3]}), scale, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[4], v[5]}), scale, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[6], v[7]}), scale, true);
+    return (long)(unsigned long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+};
+
 // ---- error plumbing -------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define MI_CHECK_ARG(cond, ...)                \

@@ -75,6 +75,7 @@ struct FgArgs {
   const bf16* y; bf16* out; float* mean; float* rstd;
   const bf16* w1p; const bf16* w2p; const float* wdp; const float* b2;
   int B, H, W, nch, with_bias, tiles_x, tiles_y, dbg, xcd_pairs;
+  float f8_x1, f8_w1, f8_x2, f8_w2;    // fp8 operand form: scales of the normalised input, W_in', the gated hidden tensor, W_out
 };
 
 // packed-weight blob layout (bytes from its base), shared by the pack kernel and the launcher
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
   }
 }
 
-template <int C, int TH, int TW, int PC, int NW>
+template <int C, int TH, int TW, int PC, int NW, bool F8>
 __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
   using K = FgCfg<C, TH, TW, PC, NW>;
   constexpr int NT = K::NT;
@@ -318,6 +319,16 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
     }
     return;
   }
+  // MFMA A operands of GEMM1 in their final form (bf16 as they are; fp8: converted once, here)
+  using Op = MfmaOp<F8>;
+  Op::enter();
+  typename Op::Frag xaf[K::MTW][K::KS32 > 0 ? K::KS32 : 1], xtf[K::MTW];
+#pragma unroll
+  for (int i = 0; i < K::MTW; ++i) {
+#pragma unroll
+    for (int ks = 0; ks < K::KS32; ++ks) xaf[i][ks] = Op::cvt(xa[i][ks], a.f8_x1);
+    xtf[i] = Op::cvt(cat8(xt[i], (s16x4){0, 0, 0, 0}), a.f8_x1);
+  }
   __syncthreads();                                     // the staged y is dead: the region becomes h0 / g / weights
 
   constexpr int W1V = K::W1_BYTES / 16, W2V = K::W2_BYTES / 16, WDV = K::WD_BYTES / 16;
@@ -358,6 +369,11 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
           bw[ks] = cat8(*reinterpret_cast<const s16x4*>(wr + ks * 32), *reinterpret_cast<const s16x4*>(wr + ks * 32 + 16));
         if (K::KT16) bt = *reinterpret_cast<const s16x4*>(wr + K::KS32 * 32);
         const float bias = *reinterpret_cast<const float*>(&W1[row * K::W1S + C]);
+        typename Op::Frag bwf[K::KS32 > 0 ? K::KS32 : 1], btf;
+#pragma unroll
+        for (int ks = 0; ks < K::KS32; ++ks) bwf[ks] = Op::cvt(bw[ks], a.f8_w1);
+        btf = Op::cvt(cat8(bt, (s16x4){0, 0, 0, 0}), a.f8_w1);
+        const float os1 = F8 ? a.f8_x1 * a.f8_w1 : 1.f;
         bf16* hrow = &H0[row * K::PLANE + 4 * g];
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i) {
@@ -365,10 +381,11 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
           if (mt < K::MT) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < K::KS32; ++ks) d = mfma32(xa[i][ks], bw[ks], d);
+            for (int ks = 0; ks < K::KS32; ++ks) d = Op::mma(xaf[i][ks], bwf[ks], d);
             // a 16-deep tail rides in a zero-padded 32-deep MFMA: a dependent chain that mixes the 16x16x32 and
             // 16x16x16 shapes returned garbage accumulators on gfx950 (ROCm 7.2) - one opcode per accumulator chain
-            if (K::KT16) d = mfma32(cat8(xt[i], (s16x4){0, 0, 0, 0}), cat8(bt, (s16x4){0, 0, 0, 0}), d);
+            if (K::KT16) d = Op::mma(xtf[i], btf, d);
+            if (F8) d *= os1;
             const unsigned m = (unsigned)(vmask >> (4 * i));
             u32x2 o;
             o[0] = pack_bf2((m & 1u) ? d[0] + bias : 0.f, (m & 2u) ? d[1] + bias : 0.f);
@@ -475,6 +492,9 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
         if (PC == 32) bo[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), *reinterpret_cast<const s16x4*>(wr + 16));
         else bo[ct] = cat8(*reinterpret_cast<const s16x4*>(wr), (s16x4){0, 0, 0, 0});   // 16 pairs: zero-padded k
       }
+      typename Op::Frag bof[K::CT];
+#pragma unroll
+      for (int ct = 0; ct < K::CT; ++ct) bof[ct] = Op::cvt(bo[ct], a.f8_w2);
 #pragma unroll
       for (int j = 0; j < K::RPW; ++j) {
         const bf16* gp = &G[(4 * g + qq) * K::GS + (wv + NW * j) * TW + 4 * pp];
@@ -488,9 +508,11 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
         if constexpr (K::QT == 4) lds_wait(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
         else lds_wait(lo[0], lo[1], hi[0], hi[1]);
 #pragma unroll
-        for (int q = 0; q < K::QT; ++q)
+        for (int q = 0; q < K::QT; ++q) {
+          const typename Op::Frag gf = Op::cvt(cat8(lo[q], hi[q]), a.f8_x2);
 #pragma unroll
-          for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = mfma32(cat8(lo[q], hi[q]), bo[ct], acc[j][q][ct]);
+          for (int ct = 0; ct < K::CT; ++ct) acc[j][q][ct] = Op::mma(gf, bof[ct], acc[j][q][ct]);
+        }
       }
     }
   }
@@ -522,7 +544,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
       for (int ct = 0; ct < K::CT; ++ct) {
 #pragma unroll
         for (int q = 0; q < K::QT; ++q) {
-          float v[4] = {acc[j][q][ct][0], acc[j][q][ct][1], acc[j][q][ct][2], acc[j][q][ct][3]};
+          const float os2 = F8 ? a.f8_x2 * a.f8_w2 : 1.f;
+          float v[4] = {acc[j][q][ct][0] * os2, acc[j][q][ct][1] * os2, acc[j][q][ct][2] * os2, acc[j][q][ct][3] * os2};
           Vec<float, 4>::st(&slab[li * K::SLAB_OS + 16 * q + 4 * g], v);
         }
         wave_sync();
@@ -576,9 +599,9 @@ static FgKind fg_kind(const mi_gdfn_fused_shape* s) {
   return FG_NONE;
 }
 
-template <int C, int TH, int TW, int PC, int NW>
+template <int C, int TH, int TW, int PC, int NW, bool F8 = false>
 static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const void* pack, const void* y, void* out,
-                     float* mean, float* rstd, hipStream_t st) {
+                     float* mean, float* rstd, hipStream_t st, const mi_f8_scales* f8 = nullptr) {
   using K = FgCfg<C, TH, TW, PC, NW>;
   FgArgs a;
   const unsigned char* pk = (const unsigned char*)pack;
@@ -587,15 +610,16 @@ static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const 
   a.wdp = (const float*)(pk + l.wdp); a.b2 = (const float*)(pk + l.b2);
   a.B = s->B; a.H = s->H; a.W = s->W; a.nch = l.nch; a.with_bias = s->ln_with_bias;
   a.tiles_x = s->W / TW; a.tiles_y = s->H / TH;
+  a.f8_x1 = f8 ? f8->x1 : 1.f; a.f8_w1 = f8 ? f8->w1 : 1.f; a.f8_x2 = f8 ? f8->x2 : 1.f; a.f8_w2 = f8 ? f8->w2 : 1.f;
   { const char* e = getenv("MI_FG_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const int64_t tiles = (int64_t)s->B * a.tiles_x * a.tiles_y;
   MI_CHECK_ARG(tiles < (1ll << 31), "gdfn_fused: grid too large");
   a.xcd_pairs = (TW == 32 && tiles % 16 == 0 && !getenv("MI_FG_NOXCD")) ? 1 : 0;
-  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW, F8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES));
   const double N = (double)s->H * s->W * s->B, h = s->hidden;
   ProfScope ps(st, K_GDFN_FUSED_FWD, 2.0 * C * N * 2.0, 2.0 * N * (3.0 * C * h) + 2.0 * N * 9.0 * 2.0 * h);
-  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, TW, PC, NW>), dim3((unsigned)tiles), dim3(64 * NW), K::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, TW, PC, NW, F8>), dim3((unsigned)tiles), dim3(64 * NW), K::LDS_BYTES, st, a);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -661,5 +685,28 @@ extern "C" int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack,
   FG_CASE(96, 8, 64, 16, 8);
 #undef FG_CASE
   set_error("gdfn_fused_fwd: no kernel for C=%d th=%d tw=%d pc=%d", s->C, f.th, f.tw, f.pc);
+  return MI_ERR_ARG;
+}
+
+// The same launch with fp8 (e4m3) MFMA operands in both projections (inference; default tile forms only).  f8->x1 scales the
+// NORMALISED input ((y - mu) rstd, |.| <= sqrt(C)) and f8->w1 the packed W_in . diag(gamma); x2 / w2 as in mi_gdfn_fwd_f8.
+extern "C" int mi_gdfn_fused_fwd_f8(const mi_gdfn_fused_shape* s, const void* pack, const mi_f8_scales* f8, const void* y, void* out,
+                                    void* stream) {
+  const FgKind k = fg_kind(s);
+  MI_CHECK_ARG(k != FG_NONE, "gdfn_fused_fwd_f8: shape not covered by the fused kernels (mi_gdfn_fused_ok)");
+  MI_CHECK_ARG(pack && y && out && f8, "gdfn_fused_fwd_f8: null pointer");
+  MI_CHECK_ARG(f8->x1 > 0.f && f8->w1 > 0.f && f8->x2 > 0.f && f8->w2 > 0.f, "gdfn_fused_fwd_f8: fp8 scales must be positive");
+  MI_CHECK_ARG(aligned16(pack) && aligned16(y) && aligned16(out), "gdfn_fused_fwd_f8: pointers must be 16-byte aligned");
+  const FgSel f = fg_select(s->C, s->H);
+  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, f.pc);
+  hipStream_t st = (hipStream_t)stream;
+#define FG8_CASE(CC, TH, TW, PC, NW) \
+  if (s->C == CC && f.th == TH && f.tw == TW && f.pc == PC && f.nw == NW) \
+    return fg_launch<CC, TH, TW, PC, NW, true>(s, l, pack, y, out, nullptr, nullptr, st, f8)
+  FG8_CASE(48, 16, 32, 16, 4);
+  FG8_CASE(48, 8, 32, 16, 4);
+  FG8_CASE(96, 8, 32, 16, 4);
+#undef FG8_CASE
+  set_error("gdfn_fused_fwd_f8: fp8 operands are built for the default tile forms only (C=%d th=%d tw=%d pc=%d)", s->C, f.th, f.tw, f.pc);
   return MI_ERR_ARG;
 }

@@ -608,34 +608,8 @@ __device__ __forceinline__ s16x8 pww_w_frag(const bf16* wr) {
   const s16x4 lo = *reinterpret_cast<const s16x4*>(wr), hi = *reinterpret_cast<const s16x4*>(wr + 16);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-// MFMA operand policy of the wave-owned kernels.  bf16: fragments go to v_mfma_f32_16x16x32_bf16 as they are.  fp8 (mi_pw_desc.f8):
-// the SAME fragments (8 bf16 along k per lane) are divided by a power-of-two scale and rounded to OCP e4m3 in registers - four
-// v_cvt_scalef32_pk_fp8_bf16 per fragment, element e to byte e for A and B alike, so the k-slot order carries over - and go to
-// v_mfma_f32_16x16x32_fp8_fp8.  X is converted once per tile, W once per use (it stays bf16 in LDS).  The conversion returns NaN
-// past +-448 unless MODE.FP16_OVFL is set (measured: tools/microbench/f8_probe.hip): the fp8 kernels set it, so a scale that is
-// too small saturates instead of poisoning the image.
-template <bool F8> struct PwwOp;
-template <> struct PwwOp<false> {
-  using Frag = s16x8;
-  static __device__ __forceinline__ void enter() {}
-  static __device__ __forceinline__ Frag cvt(const s16x8 v, float) { return v; }
-  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct PwwOp<true> {
-  using Frag = long;
-  typedef short s16x2_t __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }   // MODE.FP16_OVFL = 1
-  static __device__ __forceinline__ Frag cvt(const s16x8 v, float scale) {
-    s16x2_t lo = {0, 0}, hi = {0, 0};
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[0], v[1]}), scale, false);
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[2], v[3]}), scale, true);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[4], v[5]}), scale, false);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2_t, (s16x2_t){v[6], v[7]}), scale, true);
-    return (long)(unsigned long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
-  }
-  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
-};
+// (MFMA operand policy - bf16 fragments as they are, or converted to fp8 e4m3 in registers: MfmaOp<F8> in common.h)
+template <bool F8> using PwwOp = MfmaOp<F8>;
 // packed weight image of this workgroup's slice -> LDS, chunk images back to back ([tile][chunk][tm][WS_ROW])
 __device__ __forceinline__ void pww_stage_weights(bf16* Wl, const bf16* wpk, int images, int tm, int chunk_stride_elems, int t) {
   const int vpc = tm * PwRow<bf16>::WS_ROW / 8;

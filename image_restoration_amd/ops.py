@@ -532,11 +532,19 @@ def gdfn_fused_pack(x_like: Tensor, ln_w: Tensor, ln_b: Optional[Tensor], params
     return pack
 
 
-def gdfn_fused_fwd(y: Tensor, pack: Tensor, hidden: int, with_bias: bool, want_stats: bool = False):
-    """out = y + GDFN(LN(y)) in one launch; optionally the LN statistics [B, H*W] of y."""
+def gdfn_fused_fwd(y: Tensor, pack: Tensor, hidden: int, with_bias: bool, want_stats: bool = False,
+                   f8: Optional[F8ScalesT] = None):
+    """out = y + GDFN(LN(y)) in one launch; optionally the LN statistics [B, H*W] of y.  f8 = (x1, w1, x2, w2): fp8 e4m3 MFMA
+    operands in both projections (inference: no statistics); x1 scales the normalised input, w1 the packed W_in . diag(gamma)."""
     _gpu(y, pack)
     s = _gdfn_fused_shape(y, hidden, with_bias)
     out = torch.empty_like(y)
+    if f8 is not None:
+        if want_stats:
+            raise ValueError("fp8 projections are an inference path: no statistics")
+        L.check(L.lib().mi_gdfn_fused_fwd_f8(C.byref(s), _p(pack), C.byref(L.F8Scales(*[float(v) for v in f8])), _p(y), _p(out),
+                                             _stream()), "gdfn_fused_fwd_f8")
+        return out, None, None
     mean = rstd = None
     if want_stats:
         mean = torch.empty((y.shape[0], y.shape[2] * y.shape[3]), dtype=torch.float32, device=y.device)

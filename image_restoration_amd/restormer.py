@@ -13,6 +13,7 @@ in place and reports no autograd gradient for the parameters; otherwise ordinary
 """
 from __future__ import annotations
 
+import math
 import numbers
 import os
 import threading
@@ -221,7 +222,6 @@ F8_COUNTS = {"f8": 0, "bf16": 0}       # projections run in each form since the 
 
 
 def _f8_pow2(bound: float) -> float:
-    import math
     return 2.0 ** math.ceil(math.log2(max(float(bound), 1e-30) / F8_MAX))
 
 
@@ -252,6 +252,12 @@ def fp8_calibrate(model, samples: Sequence[Tensor]) -> None:
                             b.ffn.project_out.weight.detach().abs().max()]).tolist()
         b._f8 = {"attn": (_f8_pow2(F8_HEADROOM * a[0]), _f8_pow2(wmax[0]), _f8_pow2(F8_HEADROOM * a[1]), _f8_pow2(wmax[1])),
                  "ffn": (_f8_pow2(F8_HEADROOM * a[2]), _f8_pow2(wmax[2]), _f8_pow2(F8_HEADROOM * a[3]), _f8_pow2(wmax[3]))}
+        if b.norm2.body.__class__.__name__ == "WithBias_LayerNorm":
+            # the one-launch kernel multiplies the NORMALISED input ((y - mu) rstd: at most sqrt(C) in magnitude, a hard bound)
+            # with W_in . diag(gamma)
+            win = b.ffn.project_in.weight.detach()
+            wfold = float((win.reshape(win.shape[0], -1) * b.norm2.body.weight.detach()[None, :]).abs().max())
+            b._f8["ffn_fused"] = (_f8_pow2(math.sqrt(win.shape[1])), _f8_pow2(wfold), b._f8["ffn"][2], b._f8["ffn"][3])
 
 
 def fp8_projections(model, mode: Optional[str]) -> None:
@@ -309,6 +315,10 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
         y = y if f8_a else y[0]
     hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
     if mode == "all":
+        if (ops.gdfn_fused_ok(y, hidden, ks) and "ffn_fused" in block._f8 and not os.environ.get("MI_NO_FUSED_INFER")
+                and not os.environ.get("MI_FG_CFG")):
+            F8_COUNTS["f8"] += 2                                                          # the one-launch half-block on fp8 operands
+            return ops.gdfn_fused_fwd(y, _fused_gdfn_pack(block, y, n2, ffn), hidden, wb, f8=block._f8["ffn_fused"])[0]
         ln_f = ops.gdfn_fwd_ln_ok(y, hidden, ks) and not os.environ.get("MI_NO_LN_HEAD")
         if ops.gdfn_fwd_f8_ok(y, hidden, ks, bool(ln_f)):
             F8_COUNTS["f8"] += 2

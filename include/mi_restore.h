@@ -297,6 +297,10 @@ int mi_mdta_fwd_f8(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_
 int mi_gdfn_fwd_f8_ok(const mi_gdfn_shape* s, int with_ln);
 int mi_gdfn_fwd_f8(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const mi_f8_scales* f8, const void* x,
                    const void* residual, void* out, void* ws, void* stream);
+/* mi_gdfn_fused_fwd (the one-launch LayerNorm + GDFN half-block) on fp8 operands: x1 scales the NORMALISED input
+ * ((y - mu) rstd, |.| <= sqrt(C)) and w1 the packed W_in . diag(gamma); x2 / w2 as above.  Default tile forms only. */
+int mi_gdfn_fused_fwd_f8(const mi_gdfn_fused_shape* s, const void* pack, const mi_f8_scales* f8, const void* y, void* out,
+                         void* stream);
 int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype);
 size_t mi_bwd_tail_workspace(int M, int C);
 int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
