@@ -1032,6 +1032,14 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
     }
   };
   w_load(s0);
+  float* const lnp = reinterpret_cast<float*>(Wl + 2 * SLAB + PWW_MW * PWW_PATCH);   // gamma | beta (LayerNorm on load)
+  if (q.ln_mode) {
+    for (int i = t; i < KB * PW_KC; i += NT) {
+      lnp[i] = i < p.k1 ? q.ln_w[i] : 0.f;
+      lnp[KB * PW_KC + i] = (i < p.k1 && q.ln_b) ? q.ln_b[i] : 0.f;
+    }
+    __syncthreads();
+  }
 
   PwwX x;
   x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
@@ -1052,6 +1060,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
     for (int kb = 0; kb < KB; ++kb) {
       pww_load_chunk(raw[kb], x, kb, n0, lane);
     }
+    if (q.ln_mode)                                                   // LayerNorm over K while the tile sits in the load registers
+      pww_ln_inplace<KB>(raw, x.ktot, lnp, q.ln_mode, q.ln_mean ? q.ln_mean + zb * p.n + n0 : nullptr,
+                         q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, lane);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       s16x8 a16[NF];
@@ -1268,9 +1279,9 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     MI_CHECK_ARG(d->f8_sx > 0.f && d->f8_sw > 0.f, "pw_gemm: fp8 operand scales must be positive (powers of two)");
   }
   if (d->ln_mode) {
-    MI_CHECK_ARG(pl.wave == 1 && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
+    MI_CHECK_ARG((pl.wave == 1 || pl.wave == 3) && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
                      (d->ln_mode == 1 || d->ln_mode == 2) && (d->ln_mean == nullptr) == (d->ln_rstd == nullptr),
-                 "pw_gemm: LayerNorm-on-load needs the X-resident form (bf16, 96 < M, K <= 96, one K panel, one group; "
+                 "pw_gemm: LayerNorm-on-load needs an X-resident form (bf16; 96 < M with K <= 96, or 256 <= M with K <= 192; one K panel, one group; "
                  "mi_pw_gemm_ln_ok)");
   }
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
@@ -1308,7 +1319,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
         const int64_t split = wgs >= 200 ? 1 : std::min<int64_t>(n_slabs, cdiv(256, wgs));
         slabs_per = (int)cdiv(n_slabs, split);
         wgrid.y = (unsigned)cdiv(n_slabs, slabs_per);
-        lds = (size_t)2 * pl.k_chunks * sr * row + patches;
+        lds = (size_t)2 * pl.k_chunks * sr * row + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
       }
       {
         const char* e = getenv("MI_PW_XCD");                           // A/B switch
@@ -1428,7 +1439,8 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
 
 extern "C" int mi_pw_gemm_ln_ok(const mi_pw_desc* d) {
   if (!d || pw_check(d) != MI_OK || d->k2 != 0 || d->groups != 1) return 0;
-  return pw_plan(d).wave == 1 ? 1 : 0;
+  const int w = pw_plan(d).wave;
+  return (w == 1 || w == 3) ? 1 : 0;     // the two X-resident forms
 }
 
 extern "C" int mi_pw_gemm_f8_ok(const mi_pw_desc* d) {
