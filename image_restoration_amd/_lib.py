@@ -26,7 +26,8 @@ class PwDesc(C.Structure):
                 ("y", vp), ("y_bs", c_i64), ("y_gs", c_i64),
                 ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int),
                 ("ln_w", fp), ("ln_b", fp), ("ln_mean", fp), ("ln_rstd", fp), ("ln_mode", C.c_int),
-                ("f8", C.c_int), ("f8_sx", C.c_float), ("f8_sw", C.c_float)]
+                ("f8", C.c_int), ("f8_sx", C.c_float), ("f8_sw", C.c_float),
+                ("y_split", C.c_int), ("y2", vp), ("y2_bs", c_i64), ("y2_gs", c_i64)]
 
 
 class GramDesc(C.Structure):
@@ -141,6 +142,7 @@ SIGNATURES = {
     "mi_gdfn_fwd_ln_ok": (C.c_int, [C.POINTER(GdfnShape)]),
     "mi_gdfn_fwd_ln": (C.c_int, [C.POINTER(GdfnShape), C.POINTER(GdfnParams), C.POINTER(LnHead), vp, vp, vp, vp, vp, vp]),
     "mi_pw_gemm_f8_ok": (C.c_int, [C.POINTER(PwDesc)]),
+    "mi_pw_gemm_split_ok": (C.c_int, [C.POINTER(PwDesc)]),
     "mi_mdta_fwd_f8_ok": (C.c_int, [C.POINTER(MdtaShape), C.c_int]),
     "mi_mdta_fwd_f8": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), C.POINTER(LnHead), C.POINTER(F8Scales), vp, vp, vp,
                                  vp, vp]),

@@ -219,15 +219,18 @@ __global__ __launch_bounds__(256) void attn_bwd_partial_kernel(const float* __re
 }
 
 // backward, stage 2: grid (Z).  dA = sum of the chunk partials; softmax backward dS = A (dA - rowdot); d temperature;
-// and the per-image weights of the two gradient GEMMs  dq = G1 k + D1 q,  dk = G1^T q + D2 k  with
-// G1 = temperature dS/(|q_i||k_j|), D1_i = -sum_j dS_ij S_ij/|q_i|^2, D2_j = -sum_i dS_ij S_ij/|k_j|^2.
+// and the per-image weights of the gradient GEMM(s)  dq = G1 k + D1 q,  dk = G1^T q + D2 k  with
+// G1 = temperature dS/(|q_i||k_j|), D1_i = -sum_j dS_ij S_ij/|q_i|^2, D2_j = -sum_i dS_ij S_ij/|k_j|^2,
+// as ONE [2c][2c] matrix per (image, head) acting on the stacked operand [k; q]:
+//   rows 0..c-1  (dq): [ G1    | D1 ]        rows c..2c-1 (dk): [ D2 | G1^T ]
+// so that both gradients come out of one pass over q and k (mi_pw_desc.y_split), or of two GEMMs over row halves.
 template <int CT>
 __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __restrict__ dA_part, int rchunks,
                                                               const float* __restrict__ A, const float* __restrict__ P,
                                                               const float* __restrict__ nrm,
                                                               const float* __restrict__ temperature,
-                                                              float* __restrict__ dtemp_part, float* __restrict__ wdq,
-                                                              float* __restrict__ wdk, int C, int heads) {
+                                                              float* __restrict__ dtemp_part, float* __restrict__ wd,
+                                                              int C, int heads) {
   __shared__ float colp[16 * ATTN_MAX_C];
   __shared__ float rqs[ATTN_MAX_C], rks[ATTN_MAX_C], red[4];
   const int c = C / heads;
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
     rks[j] = s2;
   }
   __syncthreads();
-  float* wq = wdq + (int64_t)z * c * 2 * c;
-  float* wk = wdk + (int64_t)z * c * 2 * c;
+  float* wq = wd + (int64_t)z * 2 * c * 2 * c;     // rows of dq
+  float* wk = wq + (int64_t)c * 2 * c;            // rows of dk
 #pragma unroll
   for (int a = 0; a < CT; ++a) {
     const int i = ti + 16 * a;
@@ -334,11 +337,11 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
       const float nq = nz[i], nk = nz[c + j];
       const float g1 = temp * acc[a][q] / (nq * nk);
       wq[i * 2 * c + j] = g1;            // dq_i += g1 * k_j
-      wk[j * 2 * c + i] = g1;            // dk_j += g1 * q_i
+      wk[j * 2 * c + c + i] = g1;        // dk_j += g1 * q_i
       // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
       const float nki = nz[c + i];
       wq[i * 2 * c + c + j] = (i == j) ? ((nq > NORM_EPS) ? -rqs[i] / (nq * nq) : 0.f) : 0.f;
-      wk[i * 2 * c + c + j] = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
+      wk[i * 2 * c + j] = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
     }
   }
 }
@@ -420,7 +423,7 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
 
 // scratch: attn_bwd_scratch_floats() floats for the per-chunk dA partials
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
-                          const float* wo, float* dwo_part, float* dtemp_part, float* wdq, float* wdk, float* scratch,
+                          const float* wo, float* dwo_part, float* dtemp_part, float* wd, float* scratch,
                           int B, int C, int heads, hipStream_t st) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
@@ -435,7 +438,7 @@ int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const
     hipLaunchKernelGGL((attn_bwd_partial_kernel<CT>), dim3(B * heads, rch), dim3(256), lds, st, dM, A, wo, scratch, dwo_part, C,
                        heads, ld);
     hipLaunchKernelGGL((attn_bwd_finish_kernel<CT>), dim3(B * heads), dim3(256), 0, st, (const float*)scratch, rch, A, P, nrm,
-                       temperature, dtemp_part, wdq, wdk, C, heads);
+                       temperature, dtemp_part, wd, C, heads);
   });
   MI_LAUNCH_CHECK();
   return MI_OK;

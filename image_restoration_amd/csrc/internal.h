@@ -12,11 +12,12 @@ struct PwK {
   const void* r; int64_t r_bs, r_gs;
   void* y; int64_t y_bs, y_gs;
   int m; int64_t n; int groups; int vec_ok;
+  void* y2; int64_t y2_bs, y2_gs; int y_split;   // rows >= y_split go to y2 (wave-owned forms, no residual); 0 = one output
 };
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
                      float* nrm, float* M, int B, int C, int heads, hipStream_t st);
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
-                          const float* wo, float* dwo_part, float* dtemp_part, float* wdq, float* wdk, float* scratch,
+                          const float* wo, float* dwo_part, float* dtemp_part, float* wd, float* scratch,
                           int B, int C, int heads, hipStream_t st);
 size_t attn_bwd_scratch_floats(int B, int C, int heads);
 size_t chan_sum_workspace(int C, int64_t N);

@@ -77,7 +77,7 @@ struct QkvView { const void* q; int64_t q_bs; const void* k; int64_t k_bs; const
 struct AttnDims { int B, C, heads, dtype; int64_t N; };
 struct AttnSaved { float* A; float* P; float* nrm; float* M; };
 struct AttnScratch {
-  float* graw; float* ss; float* dM; float* dwo_part; float* dtemp_part; float* wdq; float* wdk; float* attn_scr;
+  float* graw; float* ss; float* dM; float* dwo_part; float* dtemp_part; float* wd; float* attn_scr;
   void* gram_ws; void* pw_ws; void* cs_ws;
 };
 
@@ -118,17 +118,23 @@ static mi_gram_desc wgrad_gram(const void* dy, int m, const void* x, int k, int 
   g.sum_batch = 1; g.accumulate = accumulate; g.out = out; g.out_ld = k; g.out_zs = 0;
   return g;
 }
-// the grouped per-image GEMM of the q/k gradients (two K-panels of c rows each, weights [Z][c][2c])
-static mi_pw_desc attn_dqk_desc(const AttnDims& d, const void* xa, int64_t xa_bs, const void* xb, int64_t xb_bs,
-                                const float* w, void* y, int64_t y_bs) {
+// the grouped per-image GEMM(s) of the q/k gradients over the stacked operand [k; q] (two K-panels of c rows each); weights
+// [Z][2c][2c] (attn_bwd_finish_kernel): rows 0..c-1 give dq, rows c..2c-1 give dk.  rows = 2c with a second output: both in one pass.
+static mi_pw_desc attn_dqk_desc(const AttnDims& d, const QkvView& v, const float* w, int row0, int rows, void* y, int64_t y_bs) {
   const int c = d.C / d.heads;
   mi_pw_desc dd;
   memset(&dd, 0, sizeof(dd));
-  dd.x1 = xa; dd.x1_bs = xa_bs; dd.x1_gs = (int64_t)c * d.N; dd.k1 = c;
-  dd.x2 = xb; dd.x2_bs = xb_bs; dd.x2_gs = (int64_t)c * d.N; dd.k2 = c;
-  dd.w = w; dd.w_bs = (int64_t)d.heads * c * 2 * c; dd.w_gs = (int64_t)c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
+  dd.x1 = v.k; dd.x1_bs = v.k_bs; dd.x1_gs = (int64_t)c * d.N; dd.k1 = c;
+  dd.x2 = v.q; dd.x2_bs = v.q_bs; dd.x2_gs = (int64_t)c * d.N; dd.k2 = c;
+  dd.w = w + (int64_t)row0 * 2 * c; dd.w_bs = (int64_t)d.heads * 2 * c * 2 * c; dd.w_gs = (int64_t)2 * c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
   dd.y = y; dd.y_bs = y_bs; dd.y_gs = (int64_t)c * d.N;
-  dd.m = c; dd.n = d.N; dd.batch = d.B; dd.groups = d.heads; dd.dtype = d.dtype;
+  dd.m = rows; dd.n = d.N; dd.batch = d.B; dd.groups = d.heads; dd.dtype = d.dtype;
+  return dd;
+}
+static mi_pw_desc attn_dqk_merged(const AttnDims& d, const QkvView& v, const float* w, void* dq, int64_t dq_bs, void* dk, int64_t dk_bs) {
+  const int c = d.C / d.heads;
+  mi_pw_desc dd = attn_dqk_desc(d, v, w, 0, 2 * c, dq, dq_bs);
+  dd.y_split = c; dd.y2 = dk; dd.y2_bs = dk_bs; dd.y2_gs = (int64_t)c * d.N;
   return dd;
 }
 
@@ -139,8 +145,7 @@ static void attn_scratch_carve(Carver& cv, const AttnDims& d, AttnScratch* w) {
   w->dM = cv.take<float>(fbytes(B * C * C));
   w->dwo_part = cv.take<float>(fbytes(B * C * C));
   w->dtemp_part = cv.take<float>(fbytes(Z));
-  w->wdq = cv.take<float>(fbytes(Z * c * 2 * c));
-  w->wdk = cv.take<float>(fbytes(Z * c * 2 * c));
+  w->wd = cv.take<float>(fbytes(Z * 2 * c * 2 * c));     // [Z][2c][2c]: rows of dq, then rows of dk, over the stacked [k; q]
   w->attn_scr = cv.take<float>(fbytes(attn_bwd_scratch_floats((int)B, (int)C, d.heads)));
   QkvView fake{(void*)256, 0, (void*)256, 0, (void*)256, 0};
   mi_gram_desc g1 = attn_qk_gram(d, fake, (float*)256, (float*)256);
@@ -157,8 +162,10 @@ static size_t attn_gram_ws_bytes(const AttnDims& d) {
 static size_t attn_pw_ws_bytes(const AttnDims& d) {
   mi_pw_desc b = conv1x1((void*)256, d.C, (const float*)256, false, d.C, nullptr, nullptr, (void*)256, d.C, d.B, d.N, d.dtype);
   b.w_bs = (int64_t)d.C * d.C;  // per-image C x C (M_b and its transpose)
-  mi_pw_desc q = attn_dqk_desc(d, (void*)256, 0, (void*)256, 0, (const float*)256, (void*)256, 0);
-  return max2(mi_pw_gemm_workspace(&b), mi_pw_gemm_workspace(&q));
+  QkvView fake{(void*)256, 0, (void*)256, 0, (void*)256, 0};
+  mi_pw_desc q = attn_dqk_desc(d, fake, (const float*)256, 0, d.C / d.heads, (void*)256, 0);
+  mi_pw_desc q2 = attn_dqk_merged(d, fake, (const float*)256, (void*)256, 0, (void*)256, 0);
+  return max2(max2(mi_pw_gemm_workspace(&b), mi_pw_gemm_workspace(&q)), mi_pw_gemm_workspace(&q2));
 }
 
 // out = (residual?) + project_out(softmax(temperature * q^ k^T) v)        Restormer.py:121-131
@@ -186,15 +193,22 @@ static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, 
   if (g_proj_b) MI_TRY(launch_chan_sum(dout, g_proj_b, B, C, d.N, d.dtype, acc, w.cs_ws, st));
   mi_gram_desc g1 = attn_dm_gram(d, dout, v, w.dM);  // dM_b = dY V^T
   MI_TRY(mi_gram(&g1, w.gram_ws, stream));
-  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, w.dwo_part, w.dtemp_part, w.wdq, w.wdk,
+  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, w.dwo_part, w.dtemp_part, w.wd,
                                w.attn_scr, B, C, hd, st));
   MI_TRY(launch_reduce_rows(w.dwo_part, g_proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
   MI_TRY(launch_reduce_rows(w.dtemp_part, g_temperature, B, hd, hd, acc, 1.0f, st));
   // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
-  mi_pw_desc dd = attn_dqk_desc(d, v.k, v.k_bs, v.q, v.q_bs, w.wdq, dq, dq_bs);
-  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
-  dd = attn_dqk_desc(d, v.q, v.q_bs, v.k, v.k_bs, w.wdk, dk, dk_bs);
-  MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+  // both in one pass over q and k where the GEMM form can write two outputs (bf16 wave-owned forms), else one GEMM each
+  const int c = C / hd;
+  mi_pw_desc dd = attn_dqk_merged(d, v, w.wd, dq, dq_bs, dk, dk_bs);
+  if (mi_pw_gemm_split_ok(&dd) && !getenv("MI_ATTN_DQK_SPLIT")) {
+    MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+  } else {
+    dd = attn_dqk_desc(d, v, w.wd, 0, c, dq, dq_bs);
+    MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+    dd = attn_dqk_desc(d, v, w.wd, c, c, dk, dk_bs);
+    MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
+  }
   // dv = M_b^T dY
   mi_pw_desc dvd = conv1x1(dout, C, sv.M, true, C, nullptr, nullptr, dv, C, B, d.N, d.dtype);
   dvd.w_bs = (int64_t)C * C;

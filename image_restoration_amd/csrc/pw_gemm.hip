@@ -618,7 +618,11 @@ __device__ __forceinline__ void pww_stage_weights(bf16* Wl, const bf16* wpk, int
     reinterpret_cast<u32x4*>(Wl)[v] = reinterpret_cast<const u32x4*>(wpk + (int64_t)c * chunk_stride_elems)[o];
   }
 }
-struct PwwOut { bf16* y; const bf16* r; const float* bias; int m; int64_t n; };
+struct PwwOut { bf16* y; const bf16* r; const float* bias; int m; int64_t n; bf16* y2; int split; };
+// output row m: rows past `split` belong to the second output tensor (mi_pw_desc.y_split: two results of one pass over X)
+__device__ __forceinline__ bf16* pww_out_row(const PwwOut& o, int m) {
+  return (o.split > 0 && m >= o.split) ? o.y2 + (int64_t)(m - o.split) * o.n : o.y + (int64_t)m * o.n;
+}
 __device__ __forceinline__ void pww_load_res(u32x4 (&rr)[2], const PwwOut& o, int mbase, int64_t n0, int lane) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -652,7 +656,7 @@ __device__ __forceinline__ void pww_store_frag(const f32x4 (&acc)[4], const u32x
         v[2 * j] += bv + bf16_bits_to_f32(rv[j] & 0xffffu);
         v[2 * j + 1] += bv + bf16_bits_to_f32(rv[j] >> 16);
       }
-      Vec<bf16, 8>::st(o.y + (int64_t)m * o.n + n0 + e_col, v);
+      Vec<bf16, 8>::st(pww_out_row(o, m) + n0 + e_col, v);
     }
   }
   wave_lds_sync();
@@ -680,7 +684,7 @@ __device__ __forceinline__ void pww_store_bf16(const f32x4 (&acc0)[4], const f32
   for (int it = 0; it < 2 * NFR; ++it) {
     const int row = it * 8 + e_row;
     const u32x4 v = *reinterpret_cast<const u32x4*>(&patch[row * PWW_XS + e_col]);
-    if (mbase + row < o.m) *reinterpret_cast<u32x4*>(o.y + (int64_t)(mbase + row) * o.n + n0 + e_col) = v;
+    if (mbase + row < o.m) *reinterpret_cast<u32x4*>(pww_out_row(o, mbase + row) + n0 + e_col) = v;
   }
   wave_lds_sync();
 }
@@ -791,6 +795,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
   PwwOut o;
   o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.y2 = p.y2 ? (bf16*)p.y2 + zb * p.y2_bs + zg * p.y2_gs : nullptr; o.split = p.y_split;
   o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
   o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
   o.m = p.m; o.n = p.n;
@@ -898,6 +903,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
   PwwOut o;
   o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.y2 = p.y2 ? (bf16*)p.y2 + zb * p.y2_bs + zg * p.y2_gs : nullptr; o.split = p.y_split;
   o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
   o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
   o.m = p.m; o.n = p.n;
@@ -1047,6 +1053,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
   x.k1 = p.k1; x.ktot = p.k1 + p.k2; x.n = p.n;
   PwwOut o;
   o.y = (bf16*)p.y + zb * p.y_bs + zg * p.y_gs;
+  o.y2 = p.y2 ? (bf16*)p.y2 + zb * p.y2_bs + zg * p.y2_gs : nullptr; o.split = p.y_split;
   o.r = p.r ? (const bf16*)p.r + zb * p.r_bs + zg * p.r_gs : nullptr;
   o.bias = p.bias ? p.bias + zg * p.bias_gs : nullptr;
   o.m = p.m; o.n = p.n;
@@ -1166,7 +1173,7 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
       const char* xw = getenv("MI_PW_XWIDE");                          // A/B switch
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches + 768 <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
-      } else if (d->m >= 256 && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {
+      } else if (d->m >= (d->y_split ? 192 : 256) && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {
         pl.wave = 3; pl.tm = 64;                                       // X-resident, W streamed (K = 97 .. 192, wide outputs)
       } else {
         // stream: one 96- / 64- / 48-channel tile per workgroup; wide outputs tile M (every tile streams X again, like the
@@ -1274,6 +1281,11 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   q.ln_w = d->ln_w; q.ln_b = d->ln_b; q.ln_mean = d->ln_mean; q.ln_rstd = d->ln_rstd; q.ln_mode = d->ln_mode;
   q.f8_sx = d->f8_sx; q.f8_sw = d->f8_sw;
   q.xcd_map = 0;
+  if (d->y_split) {
+    MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: a split output needs a wave-owned bf16 form (mi_pw_gemm_split_ok)");
+    MI_CHECK_ARG(d->y2 && !d->r && d->y_split > 0 && d->y_split < d->m && aligned16(d->y2) && d->y2_bs % 8 == 0 && d->y2_gs % 8 == 0,
+                 "pw_gemm: split output: y2 (16-byte aligned), 0 < y_split < m, no residual");
+  }
   if (d->f8) {
     MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: fp8 operands need a wave-owned bf16 form (mi_pw_gemm_f8_ok)");
     MI_CHECK_ARG(d->f8_sx > 0.f && d->f8_sw > 0.f, "pw_gemm: fp8 operand scales must be positive (powers of two)");
@@ -1429,6 +1441,7 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   k.r = d->r; k.r_bs = d->r_bs; k.r_gs = d->r_gs;
   k.y = d->y; k.y_bs = d->y_bs; k.y_gs = d->y_gs;
   k.m = d->m; k.n = d->n; k.groups = d->groups;
+  k.y2 = d->y2; k.y2_bs = d->y2_bs; k.y2_gs = d->y2_gs; k.y_split = d->y_split;
   const bool ok = pw_vec_ok(d);
   k.vec_ok = ok ? 1 : 0;
   const PwPlan pl = pw_plan(d);
@@ -1441,6 +1454,11 @@ extern "C" int mi_pw_gemm_ln_ok(const mi_pw_desc* d) {
   if (!d || pw_check(d) != MI_OK || d->k2 != 0 || d->groups != 1) return 0;
   const int w = pw_plan(d).wave;
   return (w == 1 || w == 3) ? 1 : 0;     // the two X-resident forms
+}
+
+extern "C" int mi_pw_gemm_split_ok(const mi_pw_desc* d) {
+  if (!d || pw_check(d) != MI_OK || d->dtype != MI_BF16 || d->r) return 0;
+  return pw_plan(d).wave != 0 ? 1 : 0;
 }
 
 extern "C" int mi_pw_gemm_f8_ok(const mi_pw_desc* d) {

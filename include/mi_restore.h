@@ -121,11 +121,16 @@ typedef struct {
    * powers of two, chosen so that |X| / f8_sx and |W| / f8_sw stay <= 448.  X, Y and the residual stay bf16 in HBM.  Only
    * where mi_pw_gemm_f8_ok() says so (the wave-owned bf16 kernels); zero-initialise the struct to leave it off. */
   int f8; float f8_sx, f8_sw;
+  /* Optional second output: rows m >= y_split of the result are written to y2 (row m - y_split), the rows below to y - two
+   * results of ONE pass over X (the q and k gradients of MDTA, which multiply the same q, k planes with two per-image
+   * matrices).  No residual; only where mi_pw_gemm_split_ok() says so (the wave-owned bf16 kernels); zero = off. */
+  int y_split; void* y2; int64_t y2_bs, y2_gs;
 } mi_pw_desc;
 size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
 int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);
 int mi_pw_gemm_ln_ok(const mi_pw_desc* d);
 int mi_pw_gemm_f8_ok(const mi_pw_desc* d);
+int mi_pw_gemm_split_ok(const mi_pw_desc* d);
 
 /* Opt-in packed-weight cache.  By default every mi_pw_gemm (and every module entry point built on it) packs its weight
  * matrix into its own workspace, once per call, and the library keeps no state.  A caller that controls when the
