@@ -122,6 +122,7 @@ SIGNATURES = {
     "mi_pw_cache_enable": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "mi_pw_cache_refresh": (C.c_int, [vp]),
     "mi_pw_cache_invalidate": (C.c_int, []),
+    "mi_pw_cache_pending": (C.c_int, []),
     "mi_gram_workspace": (C.c_size_t, [C.POINTER(GramDesc)]),
     "mi_gram": (C.c_int, [C.POINTER(GramDesc), vp, vp]),
     "mi_mdta_saved_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),

@@ -1484,6 +1484,12 @@ extern "C" int mi_pw_cache_invalidate(void) {
   return MI_OK;
 }
 
+// 1 while the cache holds weights it has not packed yet (registered since the last refresh) or was invalidated
+extern "C" int mi_pw_cache_pending(void) {
+  std::lock_guard<std::mutex> lk(g_pwc.mu);
+  return (g_pwc.base && !g_pwc.jobs.empty() && (g_pwc.dirty || !g_pwc.valid)) ? 1 : 0;
+}
+
 extern "C" int mi_pw_cache_refresh(void* stream) {
   std::lock_guard<std::mutex> lk(g_pwc.mu);
   if (!g_pwc.base || g_pwc.jobs.empty()) return MI_OK;

@@ -27,6 +27,72 @@ def crop_to_multiple(img: torch.Tensor, base: int = 16) -> torch.Tensor:
     return img[..., ch // 2:h - ch + ch // 2, cw // 2:w - cw + cw // 2]
 
 
+class PackedWeights:
+    """Inference-time owner of the library's packed-weight cache (mi_pw_cache_*; the trainer owns it while training).
+
+    Every 1x1 GEMM packs its fp32 weight matrix into a bf16 LDS image - per call, unless a caller that controls when the weights
+    change lends the library a buffer.  Under ``no_grad`` they never change between calls: this object moves the model's
+    parameters into one flat buffer (the cache only trusts matrices inside a range it was given - a temporary may reuse an
+    address), lends the cache, and re-packs everything in ONE launch whenever new matrices were seen (the first forward) or the
+    parameters were written (``load_state_dict``, any in-place update: the parameters' version counters).  Use as a
+    context manager or call ``close()``: the cache is process-global."""
+
+    def __init__(self, model):
+        from . import ops
+        params = list(model.parameters())
+        dev = params[0].device
+        if dev.type != "cuda" or any(p.dtype != torch.float32 or p.device != dev for p in params):
+            raise RuntimeError("PackedWeights: fp32 parameters on one MI355X")
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                self.flat[o:o + p.numel()].copy_(p.reshape(-1))
+                p.data = self.flat[o:o + p.numel()].view(p.shape)
+        self._ops = ops
+        self._params = params
+        ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat)
+        self._version = self._weights_version()
+        self._hooks = [model.register_load_state_dict_post_hook(lambda *_: self.refresh()),
+                       model.register_forward_pre_hook(lambda *_: self._check())]
+        self._open = True
+
+    def _weights_version(self) -> int:
+        # (views made through .data do not share the flat buffer's version counter: sum the parameters' own)
+        return self.flat._version + sum(p._version for p in self._params)
+
+    def refresh(self) -> None:
+        if self._open:
+            self._ops.pw_cache_refresh()
+            self._version = self._weights_version()
+
+    def _check(self) -> None:
+        if self._open and (self._weights_version() != self._version or self._ops.pw_cache_pending()):
+            self.refresh()
+
+    def close(self) -> None:
+        if self._open:
+            self._ops.pw_cache_enable(0, self.flat.device, None)
+            for h in self._hooks:
+                h.remove()
+            self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _cells(img: torch.Tensor, tile: int, overlap: int, dtype):
     B, C, H0, W0 = img.shape
     x = img.to(dtype) if dtype is not None else img

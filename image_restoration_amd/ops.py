@@ -817,6 +817,11 @@ def pw_cache_enable(nbytes: int, device, params: Optional[Tensor] = None) -> Non
     _pw_cache_buf = buf  # keeps the memory alive for as long as the cache points at it
 
 
+def pw_cache_pending() -> bool:
+    """True while the cache holds weights it has not packed yet (seen since the last refresh) or was invalidated."""
+    return bool(L.lib().mi_pw_cache_pending())
+
+
 def pw_cache_refresh() -> None:
     L.check(L.lib().mi_pw_cache_refresh(_stream()), "pw_cache_refresh")
 

@@ -112,22 +112,29 @@ class FlatTrainer:
             ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat_p)
             # Anything that writes the parameters other than optimizer_step (load_state_dict to resume or to evaluate a
             # checkpoint, an EMA copy-back, a manual re-init) must not leave the GEMMs on stale packed images: torch bumps
-            # the flat buffer's version counter on every in-place write through a view, the fused AdamW kernel (a raw
-            # pointer write) does not, so a version change seen at the next forward means "somebody else wrote": re-pack.
-            self._p_version = self.flat_p._version
+            # a parameter's version counter on every in-place write, the fused AdamW kernel (a raw pointer write) does
+            # not, so a change of the summed counters seen at the next forward means "somebody else wrote": re-pack.
+            self._p_version = self._weights_version()
             model.register_load_state_dict_post_hook(lambda *_: self.weights_changed())
             model.register_forward_pre_hook(lambda *_: self._check_weights())
 
     # ------------------------------------------------------------------ packed-weight cache safety
+    def _weights_version(self) -> int:
+        """Changes whenever torch wrote a parameter in place: every parameter is a view into the flat buffer made through
+        ``.data``, which does NOT share the buffer's version counter, so the parameters' own counters are summed (plus the
+        buffer's, for writes to it directly).  The fused AdamW kernel writes through raw pointers and bumps nothing: the
+        optimizer step refreshes the cache itself."""
+        return self.flat_p._version + sum(p._version for p in self.params)
+
     def weights_changed(self) -> None:
         """Tell the trainer the parameters were written outside optimizer_step (called automatically after
         load_state_dict and whenever the flat buffer's version counter moved)."""
         if self._pack_cache:
             ops.pw_cache_refresh()
-            self._p_version = self.flat_p._version
+            self._p_version = self._weights_version()
 
     def _check_weights(self) -> None:
-        if self._pack_cache and self.flat_p._version != self._p_version:
+        if self._pack_cache and self._weights_version() != self._p_version:
             self.weights_changed()
 
     def close(self) -> None:
@@ -306,14 +313,14 @@ class FlatTrainer:
                 dist.all_gather_into_tensor(self.flat_p, p_shard, group=self.pg)     # in place: each rank's slice is its input
             if self._pack_cache and self.flat_p.is_cuda:
                 ops.pw_cache_refresh()
-                self._p_version = self.flat_p._version
+                self._p_version = self._weights_version()
             return
         if self.flat_p.is_cuda:
             ops.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.step_count, self.betas,
                            self.eps, self.wd, scale, self.dev_scalars if use_dev_scalars else None)
             if self._pack_cache:
                 ops.pw_cache_refresh()   # the weights just changed: re-pack every 1x1 weight image in one launch
-                self._p_version = self.flat_p._version
+                self._p_version = self._weights_version()
         elif self._host_update is not None:
             self._host_update(self, scale)
         else:

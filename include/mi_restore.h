@@ -150,6 +150,7 @@ int mi_pw_gemm_split_ok(const mi_pw_desc* d);
 int mi_pw_cache_enable(void* buf, size_t bytes, const void* params_lo, const void* params_hi);
 int mi_pw_cache_refresh(void* stream);
 int mi_pw_cache_invalidate(void);
+int mi_pw_cache_pending(void);   /* 1 while weights registered since the last refresh (or an invalidation) wait for one */
 
 /* ------------------------------------------------------------------------
  * Row-Gram (reduction over the pixel axis), the contraction of MDTA's q k^T

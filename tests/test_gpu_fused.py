@@ -135,6 +135,9 @@ def test_trainer_pack_cache_follows_load_state_dict():
         y_after_steps = net(x).detach().float()
         net.load_state_dict(sd0)                        # back to the initial weights, written in place into the flat buffer
         y_loaded = net(x).detach().float()
+        with torch.no_grad():                           # an in-place write that is neither a step nor a load (EMA copy-back, re-init)
+            net.attn.qkv.weight.mul_(0.5)
+        y_scaled = net(x).detach().float()
     finally:
         tr.close()
     fresh = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
@@ -142,6 +145,11 @@ def test_trainer_pack_cache_follows_load_state_dict():
     y_ref = fresh(x).detach().float()
     assert rel(y_loaded, y_ref) < 1e-6, "forward after load_state_dict used stale packed weights"
     assert rel(y_after_steps, y_ref) > 1e-4            # the steps really changed the weights
+    with torch.no_grad():
+        fresh.attn.qkv.weight.mul_(0.5)
+    y_ref2 = fresh(x).detach().float()
+    assert rel(y_ref2, y_ref) > 1e-4
+    assert rel(y_scaled, y_ref2) < 1e-6, "forward after an in-place parameter write used stale packed weights"
 
 
 # ------------------------------------------------------------------------------------------------ backward tail (bwd_tail.hip)

@@ -102,3 +102,45 @@ def test_tiled_inference_is_tile_exact_and_covers_ragged_images():
             w = min(tile, 136 - j * tile)
             got = out[:, :, i * tile:i * tile + h, j * tile:j * tile + w]
             assert float((got - ref[:, :, :h, :w].float()).abs().max()) < 2e-2     # batch composition only changes bf16 rounding paths
+
+
+def test_packed_weights_cache_for_inference_follows_the_weights():
+    """inference.PackedWeights (the library's packed 1x1 weight images kept across no_grad calls): bit-identical outputs with and
+    without it; a load_state_dict and an in-place write are both picked up before the next forward (the stale-image hazard);
+    closing it returns the library to per-call packing."""
+    import image_restoration_amd as m
+    from image_restoration_amd import inference, ops
+    from image_restoration_amd.configs import RESTORMER_TINY
+    net = m.Restormer(**RESTORMER_TINY)
+    net.load_state_dict(R.make_restormer_state(RESTORMER_TINY, seed=3))
+    net = net.to(DEV).eval()
+    # (128 x 128: every level's planes are >= 16 rows, so the whole network runs on the native kernels - the 8 x 8 planes of a 64 x 64
+    #  input would send the latent-level 3x3 convs through torch / MIOpen, whose results are not bit-reproducible from run to run)
+    x = torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(4)).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        ref1 = net(x).float()
+        assert torch.equal(net(x).float(), ref1)
+        with inference.PackedWeights(net) as pk:
+            a = net(x).float()                       # registers the matrices, packs per call
+            assert ops.pw_cache_pending()
+            b = net(x).float()                       # refreshed by the pre-hook, then served from the cache
+            assert not ops.pw_cache_pending()
+            assert torch.equal(a, ref1) and torch.equal(b, ref1)
+            sd2 = R.make_restormer_state(RESTORMER_TINY, seed=5)
+            net.load_state_dict(sd2)
+            c = net(x).float()
+            for p in net.parameters():               # an in-place write outside load_state_dict
+                p.mul_(1.5)
+                break
+            d = net(x).float()
+        e = net(x).float()                           # cache closed: per-call packing again
+        ref2 = m.Restormer(**RESTORMER_TINY)
+        ref2.load_state_dict(sd2)
+        ref2 = ref2.to(DEV).eval()
+        r2 = ref2(x).float()
+        assert torch.equal(c, r2), float((c - r2).abs().max())
+        assert not torch.equal(c, ref1)
+        next(ref2.parameters()).mul_(1.5)
+        want = ref2(x).float()
+        assert torch.equal(d, want), float((d - want).abs().max())
+        assert torch.equal(e, want), float((e - want).abs().max())

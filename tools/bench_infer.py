@@ -49,6 +49,11 @@ def psnr(a, b):
 
 
 os.environ["MI_NO_FUSED_INFER"] = ""
+with inference.PackedWeights(net):
+    outp, dtp = timed(25)
+out0, dt0 = timed(25)
+print(f"packed 1x1 weight images kept across calls (inference.PackedWeights), tile_batch 25: {dtp * 1e3:.1f} ms/image = "
+      f"{size * size / dtp / 1e6:.2f} Mpix/s  (per-call packing: {dt0 * 1e3:.1f} ms; outputs identical: {bool(torch.equal(outp, out0))})", flush=True)
 ref32 = inference.tiled_restore(net, noisy, tile_batch=4, dtype=None)            # fp32 activations: the parity path
 out16, dt16 = timed(25)
 inference.calibrate_fp8(net, noisy, max_tiles=8)
