@@ -109,6 +109,7 @@ struct PwG {
   // LayerNorm of X applied on the way in (xres form only): gamma / beta [K], statistics out [batch][n] (or null)
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;   // 0 none, 1 WithBias, 2 BiasFree
   int xcd_map;              // stream form: XCD-aware workgroup order (see the kernel)
+  int w_direct;             // wave forms: stage the weights straight from the fp32 matrix k.w (per-image weights: no pack launch)
   float f8_sx, f8_sw;       // fp8 operand forms: X / f8_sx and W / f8_sw are rounded to e4m3, the accumulator is scaled by their product
 };
 
@@ -618,6 +619,25 @@ __device__ __forceinline__ void pww_stage_weights(bf16* Wl, const bf16* wpk, int
     reinterpret_cast<u32x4*>(Wl)[v] = reinterpret_cast<const u32x4*>(wpk + (int64_t)c * chunk_stride_elems)[o];
   }
 }
+// Per-image weights (MDTA's project_out . softmax product and its transposes, the q / k gradient matrices) change with every call,
+// so a packed image of them is never reused: with MI_PW_DIRECT=1 the wave-owned kernels read such a matrix straight from fp32 and
+// round it to bf16 on the way into LDS - same values as the pack kernel, one launch less per GEMM, and measured slower (see
+// pw_launch): kept as an A/B switch.  Chunk images [img][tm][WS_ROW], img = mt * nk + kc.
+__device__ __forceinline__ void pww_stage_weights_f32(bf16* Wl, const float* __restrict__ w, int64_t sm, int64_t sk, int M, int K,
+                                                      int mt0, int n_mt, int nk, int tm, int t) {
+  constexpr int WS_ROW = PwRow<bf16>::WS_ROW;
+  const int per = tm * PW_KC, total = n_mt * nk * per;
+  for (int e = t; e < total; e += 64 * PWW_MW) {
+    const int img = e / per, r = e - img * per;
+    int mm, kk;
+    if (sk == 1) { kk = r & (PW_KC - 1); mm = r / PW_KC; }           // consecutive threads follow the unit stride of the matrix
+    else { mm = r % tm; kk = r / tm; }
+    const int mt = img / nk, kc = img - mt * nk;
+    const int m = (mt0 + mt) * tm + mm, k = kc * PW_KC + kk;
+    const float v = (m < M && k < K) ? w[(int64_t)m * sm + (int64_t)k * sk] : 0.f;
+    Wl[(img * tm + mm) * WS_ROW + kk] = (bf16)v;
+  }
+}
 struct PwwOut { bf16* y; const bf16* r; const float* bias; int m; int64_t n; bf16* y2; int split; };
 // output row m: rows past `split` belong to the second output tensor (mi_pw_desc.y_split: two results of one pass over X)
 __device__ __forceinline__ bf16* pww_out_row(const PwwOut& o, int m) {
@@ -779,8 +799,11 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   bf16* const patch = Wl + (int64_t)m_tiles * KB * TM * WS_ROW + wv * PWW_PATCH;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
-  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, m_tiles * KB, TM,
-                    chunk_stride_elems, t);
+  if (q.w_direct)
+    pww_stage_weights_f32(Wl, p.w + zb * p.w_bs + zg * p.w_gs, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, 0, m_tiles, KB, TM, t);
+  else
+    pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, m_tiles * KB, TM,
+                      chunk_stride_elems, t);
   float* const lnp = reinterpret_cast<float*>(Wl + (int64_t)m_tiles * KB * TM * WS_ROW + PWW_MW * PWW_PATCH);   // gamma | beta
   if (q.ln_mode) {
     for (int i = t; i < KB * PW_KC; i += 64 * PWW_MW) {
@@ -894,8 +917,11 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   const int z = bz, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
   const int m0 = by * TM;
-  pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
-                            (int64_t)by * nchunks * chunk_stride_elems, nchunks, TM, chunk_stride_elems, t);
+  if (q.w_direct)
+    pww_stage_weights_f32(Wl, p.w + zb * p.w_bs + zg * p.w_gs, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, by, 1, nchunks, TM, t);
+  else
+    pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
+                              (int64_t)by * nchunks * chunk_stride_elems, nchunks, TM, chunk_stride_elems, t);
   __syncthreads();
   PwwX x;
   x.x1 = (const bf16*)p.x1 + zb * p.x1_bs + zg * p.x1_gs;
@@ -1015,7 +1041,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
   const int s0 = blockIdx.y * slabs_per_wg;
   const int s1 = s0 + slabs_per_wg < n_slabs ? s0 + slabs_per_wg : n_slabs;
   u32x4 wr[VPT];
+  const float* const wf = p.w + zb * p.w_bs + zg * p.w_gs;           // (per-image weights: staged straight from fp32, see w_store)
   auto w_load = [&](int sl) {                                        // slab sl = rows [SR sl, SR sl + SR) of the packed 64-row tiles
+    if (q.w_direct) return;
     int tt = t;
     asm volatile("" : "+v"(tt));
     const int mt = sl * SR / TM, r0 = sl * SR - mt * TM;
@@ -1028,7 +1056,11 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
       }
     }
   };
-  auto w_store = [&](int buf) {
+  auto w_store = [&](int buf, int sl) {
+    if (q.w_direct) {
+      pww_stage_weights_f32(Wl + buf * SLAB, wf, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, sl, 1, KB, SR, t);
+      return;
+    }
     int tt = t;
     asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -1078,7 +1110,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
       for (int nf = 0; nf < NF; ++nf) a[kb][nf] = Op::cvt(a16[nf], q.f8_sx);
     }
   }
-  w_store(0);
+  w_store(0, s0);
   __syncthreads();
   for (int sl = s0; sl < s1; ++sl) {
     const int buf = (sl - s0) & 1;
@@ -1123,7 +1155,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
         }
       }
     }
-    if (sl + 1 < s1) w_store(buf ^ 1);
+    if (sl + 1 < s1) w_store(buf ^ 1, sl + 1);
     __syncthreads();
   }
 }
@@ -1266,8 +1298,12 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   job.M = d->m; job.K = d->k1 + d->k2; job.tm = pl.tm; job.k_chunks = pl.k_chunks;
   job.groups_w = pl.per_group ? d->groups : 1; job.chunk_elems = pl.chunk_elems; job.m_fast = d->w_sk != 1 ? 1 : 0;
   job.dtype = d->dtype; job.slices = pl.slices; job.slice_elems = pl.slice_elems;
-  const unsigned char* cached = pw_cache_lookup(job, pl.bytes, st);
-  if (!cached) {  // re-pack the weights of every slice (and refresh the zero block)
+  // MI_PW_DIRECT=1 (A/B switch, off): per-image weights on a wave-owned form without a packed image - the kernels stage them from
+  // fp32.  Measured SLOWER (profiles/r02_m_per_image_weights_direct_ab.txt: 165.0 vs 157.2 ms per step): every one of the ~2000
+  // workgroups of such a GEMM repeats the scalar fp32 -> bf16 walk that one 7 us pack launch does once.
+  const bool direct = pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && getenv("MI_PW_DIRECT");
+  const unsigned char* cached = direct ? nullptr : pw_cache_lookup(job, pl.bytes, st);
+  if (!cached && !direct) {  // re-pack the weights of every slice (and refresh the zero block)
     const int64_t total = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * PW_KC;
     int gx = cdiv(total, 256);
     if (gx > 1024) gx = 1024;
@@ -1281,6 +1317,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   q.ln_w = d->ln_w; q.ln_b = d->ln_b; q.ln_mean = d->ln_mean; q.ln_rstd = d->ln_rstd; q.ln_mode = d->ln_mode;
   q.f8_sx = d->f8_sx; q.f8_sw = d->f8_sw;
   q.xcd_map = 0;
+  q.w_direct = direct ? 1 : 0;
   if (d->y_split) {
     MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: a split output needs a wave-owned bf16 form (mi_pw_gemm_split_ok)");
     MI_CHECK_ARG(d->y2 && !d->r && d->y_split > 0 && d->y_split < d->m && aligned16(d->y2) && d->y2_bs % 8 == 0 && d->y2_gs % 8 == 0,

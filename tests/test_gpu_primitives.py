@@ -355,6 +355,11 @@ def test_pw_wave_forms_without_residual(monkeypatch, epilogue, transposed, M, K,
         outs.append(y.float().cpu())
     assert torch.equal(outs[0], ref), f"max diff {(outs[0] - ref).abs().max()}"
     assert torch.equal(outs[1], ref)
+    if per_image:                                       # A/B switch: per-image weights staged from fp32 inside the wave-owned GEMM
+        monkeypatch.setenv("MI_PW_WAVE", "1")
+        monkeypatch.setenv("MI_PW_DIRECT", "1")
+        y = _pw_raw(x1.to(DEV), None, warg.to(DEV), None if bias is None else bias.to(DEV), None, M, groups, per_image, transposed)
+        assert torch.equal(y.float().cpu(), ref)
 
 
 def test_pw_wave_forms_fuzz_against_chunked(monkeypatch):
@@ -434,3 +439,9 @@ def test_pw_xwide_form_exact_on_integers(monkeypatch, epilogue, M, K1, K2, per_i
         y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), None if bias is None else bias.to(DEV),
                     None if res is None else res.to(DEV), M, 1, per_image, transposed)
         assert torch.equal(y.float().cpu(), ref), (xwide, float((y.float().cpu() - ref).abs().max()))
+        if per_image:                                   # A/B switch: per-image weights staged from fp32 inside the GEMM
+            monkeypatch.setenv("MI_PW_DIRECT", "1")
+            y = _pw_raw(x1.to(DEV), None if x2 is None else x2.to(DEV), warg.to(DEV), None if bias is None else bias.to(DEV),
+                        None if res is None else res.to(DEV), M, 1, per_image, transposed)
+            monkeypatch.delenv("MI_PW_DIRECT")
+            assert torch.equal(y.float().cpu(), ref), ("direct", xwide)
