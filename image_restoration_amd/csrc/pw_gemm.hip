@@ -1018,13 +1018,14 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
 // 1020 x 192 141 -> 105 us, 510 x 192 (W^T) 74 -> 53 us - now bound by the output writes (3.0-3.4 TB/s of the 4.45 TB/s write roof).
 // A 32-pixel-per-wave variant for K = 193 .. 384 (fragments still 96 VGPRs) was built, parity-tested and measured: no gain at the latent
 // level (1152 x 384 66 -> 71 us, 2042 x 384 122 -> 112 us) - each weight fragment read from LDS then feeds only 2 MFMAs - and was dropped.
+constexpr int PWX_SR = 64;   // output channels per staged weight slab (32 - two workgroups per CU by LDS, twice the barriers - measured 5-12 % slower)
 template <int KB, bool F8>
 __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, int n_slabs, int slabs_per_wg, int chunk_stride_elems) {
   using Op = PwwOp<F8>;
   Op::enter();
   const PwK& p = q.k;
   constexpr int WS_ROW = PwRow<bf16>::WS_ROW, TM = 64;
-  constexpr int NF = 4, SR = 64, TNW = PW_TN;                        // pixel fragments per wave, channels per staged slab, pixels per wave
+  constexpr int NF = 4, SR = PWX_SR, TNW = PW_TN;                        // pixel fragments per wave, channels per staged slab, pixels per wave
   constexpr int VPC = SR * WS_ROW / 8;                               // 16-byte vectors per chunk image inside one slab
   constexpr int VPS = KB * VPC;
   constexpr int NT = 64 * PWW_MW;
@@ -1361,7 +1362,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
       size_t lds = wbytes + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
       int n_slabs = 0, slabs_per = 0;
       if (pl.wave == 3) {                                              // one 64-pixel tile per wave; M split only to fill the chip
-        const int sr = 64;
+        const int sr = PWX_SR;
         wgrid.x = (unsigned)cdiv(n_tiles, PWW_MW);
         n_slabs = cdiv(d->m, sr);
         const int64_t wgs = (int64_t)wgrid.x * grid.z;
