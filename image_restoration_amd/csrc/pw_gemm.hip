@@ -1206,7 +1206,7 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
       const char* xw = getenv("MI_PW_XWIDE");                          // A/B switch
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches + 768 <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
-      } else if (d->m >= (d->y_split ? 192 : 256) && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {
+      } else if (d->m >= 256 && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {   // (192 x 192 measured better on the streaming form)
         pl.wave = 3; pl.tm = 64;                                       // X-resident, W streamed (K = 97 .. 192, wide outputs)
       } else {
         // stream: one 96- / 64- / 48-channel tile per workgroup; wide outputs tile M (every tile streams X again, like the

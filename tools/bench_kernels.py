@@ -113,7 +113,35 @@ def bench_gram():
             print(f"gram+sumsq {ma}x{mb} g={g} {H}x{W}: {us:8.1f} us {(a.numel() + b.numel()) * 2 / us / 1e3:7.0f} GB/s", flush=True)
 
 
+def bench_dqk():
+    """The merged q / k gradient GEMM of MDTA: per-image [2c][2c] weights over the stacked [k; q], two outputs (y_split)."""
+    import ctypes as C
+    from image_restoration_amd import _lib as L, ops
+    B = int(os.environ.get("BK_BATCH", "8"))
+    for (c, heads, H, W) in [(48, 1, 256, 256), (96, 1, 256, 256), (48, 2, 128, 128), (48, 4, 64, 64), (48, 8, 32, 32)]:
+        Cc, N = c * heads, H * W
+        qkv = torch.randn(B, 3 * Cc, H, W, device="cuda").bfloat16()
+        dqkv = torch.empty_like(qkv)
+        w = torch.randn(B, heads, 2 * c, 2 * c, device="cuda")
+        def desc(rows, row0, y_off, split):
+            d = L.PwDesc()
+            d.x1, d.x1_bs, d.x1_gs, d.k1 = qkv.data_ptr() + Cc * N * 2, 3 * Cc * N, c * N, c      # k
+            d.x2, d.x2_bs, d.x2_gs, d.k2 = qkv.data_ptr(), 3 * Cc * N, c * N, c                    # q
+            d.w = w.data_ptr() + row0 * 2 * c * 4
+            d.w_bs, d.w_gs, d.w_sm, d.w_sk = heads * 4 * c * c, 4 * c * c, 2 * c, 1
+            d.y, d.y_bs, d.y_gs = dqkv.data_ptr() + y_off * N * 2, 3 * Cc * N, c * N
+            d.m, d.n, d.batch, d.groups, d.dtype = rows, N, B, heads, 1
+            if split:
+                d.y_split, d.y2, d.y2_bs, d.y2_gs = c, dqkv.data_ptr() + Cc * N * 2, 3 * Cc * N, c * N
+            return d
+        merged, dq, dk = desc(2 * c, 0, 0, True), desc(c, 0, 0, False), desc(c, c, Cc, False)
+        t1 = timeit(lambda: ops.pw_gemm_desc(merged, qkv.device))
+        t2 = timeit(lambda: (ops.pw_gemm_desc(dq, qkv.device), ops.pw_gemm_desc(dk, qkv.device)))
+        print(f"dq/dk c={c} heads={heads} {H}x{W}: one GEMM, two outputs {t1:8.1f} us   two GEMMs {t2:8.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pw", "ln", "dw", "gram"]
     for wname in which:
-        {"pw": bench_pw, "ln": bench_ln, "dw": bench_dw, "gram": bench_gram}[wname]()
+        {"pw": bench_pw, "ln": bench_ln, "dw": bench_dw, "gram": bench_gram, "dqk": bench_dqk}[wname]()
+
