@@ -583,8 +583,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             y = ops.col2im3x3(ops.conv1x1(x, wz), bias, residual)
             saved = x
         if _grad_mode() and any(ctx.needs_input_grad):
-            # wide inputs: keep x and rebuild its 9-plane expansion in backward instead of holding 9 Cin planes per conv
-            ctx.recol = ctx.small_in and cin > 4
+            # The weight gradient needs the 9-plane expansion of x again.  Default: keep it from the forward (1.6 GB at bs 32 over the
+            # three Upsample convs of Restormer base).  MI_CONV3_RECOL=1: the memory-lean form - for a wide input keep x only and
+            # rebuild the expansion in backward (three more im2col launches per step, ~0.9 ms).
+            ctx.recol = ctx.small_in and cin > 4 and bool(os.environ.get("MI_CONV3_RECOL"))
             ctx.save_for_backward(x if ctx.recol else saved, weight)
             ctx.has_bias = bias is not None
             ctx.mg = _main_grads((weight, bias))
