@@ -305,3 +305,36 @@ def test_ln_head_rejects_uncovered_shapes():
     assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 384, 16, 64), dtype=torch.bfloat16, device=DEV), 8, 3)   # K > 192
     assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 16, 64), dtype=torch.float32, device=DEV), 1, 3)     # fp32
     assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 10, 10), dtype=torch.bfloat16, device=DEV), 1, 3)    # ragged plane
+
+
+# ------------------------------------------------------------------------------------------------ round-2 A/B switches, bf16 step path
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 16, 64)), (192, 4, (2, 192, 16, 64)), (384, 8, (3, 384, 16, 64))])
+def test_round2_switches_leave_the_block_unchanged(c, heads, shape, monkeypatch):
+    """The bf16 training path of a TransformerBlock under the switches that select this round's alternative kernels: same output,
+    input gradient and parameter gradients as the default.  Exact where only the launch structure differs (q / k gradients as one
+    GEMM or two, per-image weights packed or staged in the GEMM); to 2e-2 of the largest value where a summation order changes
+    (weight-gradient Grams folded over the batch or not, the W-streamed GEMM form or the streaming one)."""
+    m = M()
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=91 + c)
+    x0, cot = seeded_input(shape, 7100 + c), seeded_input(shape, 7101 + c)
+
+    def run_block():
+        blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+        blk.load_state_dict(sd)
+        x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        y = blk(x)
+        y.backward(cot.to(DEV).to(torch.bfloat16))
+        return [y.detach().float(), x.grad.float()] + [p.grad.float() for _, p in sorted(blk.named_parameters())]
+
+    base = run_block()
+    for env, exact in (("MI_ATTN_DQK_SPLIT=1", True), ("MI_PW_DIRECT=1", True), ("MI_GRAM_FOLD=0", False), ("MI_GRAM_FOLD=2", False),
+                       ("MI_PW_XWIDE=0", False)):
+        name, _, val = env.partition("=")
+        monkeypatch.setenv(name, val)
+        got = run_block()
+        monkeypatch.delenv(name)
+        for i, (a, b) in enumerate(zip(got, base)):
+            if exact:
+                assert torch.equal(a, b), (env, i, float((a - b).abs().max()))
+            else:
+                assert rel(a, b) < 2e-2, (env, i, rel(a, b))
