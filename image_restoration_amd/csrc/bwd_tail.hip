@@ -248,46 +248,57 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(ap0 + 16 * nt) = d[nt];
   };
 
-  // LayerNorm backward on a finished dxn tile (LPP lanes per pixel, channels sub + LPP j), result into the dres tile in place
-  auto ln_phase = [&](const bf16* xh, bf16* dr, float rstd_p) {
+  // LayerNorm backward on a finished dxn tile, result into the dres tile in place.  A lane takes TWO adjacent pixels of its
+  // channels (c = sub + L2 j over the L2 = 2 LPP lanes of the pair): every LDS access is then a bf16 pair (4 bytes) or an fp32
+  // pair (8 bytes) - half the LDS instructions of the one-pixel form, which bounded this phase (48 two-byte accesses per lane).
+  auto ln_phase = [&](const bf16* xh, bf16* dr, f32x2 rstd_p) {
     if (a.dbg & 8) return;
     int tt = t;
     asm volatile("" : "+v"(tt));
-    const int px = tt / LPP, sub = tt % LPP;
-    // swizzled slot of (c = sub + LPP j, px): the chunk term of c splits into a lane part (sub/2) and a constant part (LPP j / 2)
-    constexpr int NVAR = 16 / LPP;                                      // distinct constant parts: LPP 8 -> {0,4}, LPP 4 -> {0,2,4,6}
-    int base[NVAR];
+    constexpr int L2 = 2 * LPP, CPL2 = C / L2;
+    static_assert(C % L2 == 0 && (L2 == 8 || L2 == 16), "pixel-pair LayerNorm phase");
+    const int px0 = 2 * (tt / L2), sub = tt % L2;
+    // swizzled slot of (c = sub + L2 j, px0): c >> 1 = (sub >> 1) + (L2 / 2) j; with L2 = 16 the j term vanishes under & 7, with
+    // L2 = 8 (sub >> 1 < 4) it toggles bit 2 for odd j
+    int base[2];
+    base[0] = sub * 64 + ((((px0 >> 3) ^ (sub >> 1)) & 7) << 3) + (px0 & 7);
+    base[1] = sub * 64 + ((((px0 >> 3) ^ (sub >> 1) ^ (L2 == 8 ? 4 : 0)) & 7) << 3) + (px0 & 7);
+    const float* const ap = &acc[sub * XS + px0];
+    f32x2 gv[CPL2], xv[CPL2], s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
-    for (int v = 0; v < NVAR; ++v) base[v] = sub * 64 + ((((px >> 3) ^ (sub >> 1) ^ ((LPP * v) >> 1)) & 7) << 3) + (px & 7);
-    const short* xs = reinterpret_cast<const short*>(xh);
-    short* ds = reinterpret_cast<short*>(dr);
-    const float* const ap = &acc[sub * XS + px];
-    float gv[CPL], xv[CPL], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      gv[j] = ap[LPP * j * XS];                                         // g = gamma dxn (gamma rides in the W^T fragments)
-      xv[j] = bf_s(xs[base[j % NVAR] + LPP * j * 64]);
+    for (int j = 0; j < CPL2; ++j) {
+      gv[j] = *reinterpret_cast<const f32x2*>(ap + L2 * j * XS);          // g = gamma dxn (gamma rides in the W^T fragments)
+      const unsigned xb = *reinterpret_cast<const unsigned*>(xh + base[j & 1] + L2 * j * 64);
+      xv[j] = (f32x2){bf_lo(xb), bf_hi(xb)};
       s1 += gv[j];
       s2 += gv[j] * xv[j];
     }
-    // sum over the LPP consecutive lanes of this pixel, every lane gets the total: DPP only (quad swaps, then the half-row
-    // mirror adds the other quad's total) - no ds_bpermute round trips on the phase's critical path
+    // sum over the L2 consecutive lanes of this pixel pair, every lane gets the totals: DPP only (quad swaps, the half-row
+    // mirror adds the other quad's total, the row mirror the other half row's) - no ds_bpermute round trips
     auto dpp = [](float v, auto ctrl) {
       return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
     };
-    s1 += dpp(s1, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-    s2 += dpp(s2, std::integral_constant<int, 0xB1>{});
-    s1 += dpp(s1, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-    s2 += dpp(s2, std::integral_constant<int, 0x4E>{});
-    if (LPP == 8) {
-      s1 += dpp(s1, std::integral_constant<int, 0x141>{});  // row_half_mirror
-      s2 += dpp(s2, std::integral_constant<int, 0x141>{});
-    }
-    const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      short* const slot = ds + base[j % NVAR] + LPP * j * 64;
-      *slot = bf_bits(rstd_p * (gv[j] - m1 - xv[j] * m2) + bf_s(*slot));
+    for (int e = 0; e < 2; ++e) {
+      float u1 = s1[e], u2 = s2[e];
+      u1 += dpp(u1, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+      u2 += dpp(u2, std::integral_constant<int, 0xB1>{});
+      u1 += dpp(u1, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+      u2 += dpp(u2, std::integral_constant<int, 0x4E>{});
+      u1 += dpp(u1, std::integral_constant<int, 0x141>{});  // row_half_mirror
+      u2 += dpp(u2, std::integral_constant<int, 0x141>{});
+      if (L2 == 16) {
+        u1 += dpp(u1, std::integral_constant<int, 0x140>{});  // row_mirror
+        u2 += dpp(u2, std::integral_constant<int, 0x140>{});
+      }
+      s1[e] = u1 * (1.0f / C); s2[e] = u2 * (1.0f / C);
+    }
+#pragma unroll
+    for (int j = 0; j < CPL2; ++j) {
+      unsigned* const slot = reinterpret_cast<unsigned*>(dr + base[j & 1] + L2 * j * 64);
+      const unsigned rb = *slot;
+      const f32x2 o = rstd_p * (gv[j] - s1 - xv[j] * s2);
+      *slot = pack_bf2(o[0] + bf_lo(rb), o[1] + bf_hi(rb));
     }
   };
   auto store_phase = [&](const bf16* dr, int b, int p0) {
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   __syncthreads();
   int buf = 0, pb = 0, pp0 = 0;
   bool have_prev = false;
-  float rstd_prev = 0.f;
+  f32x2 rstd_prev = {0.f, 0.f};
   for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
     const int b = tile / a.tiles_per_image, p0 = (tile - b * a.tiles_per_image) * 64;
     const int nxt = tile + gridDim.x;
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(dr) + (pid - XP) * 1024 + lane * 16) = zero4;
       }
     }
-    const float rstd_p = st[64 + t / LPP];                              // read before the next tile's statistics are requested
+    const f32x2 rstd_p = *reinterpret_cast<const f32x2*>(&st[64 + 2 * (t / (2 * LPP))]);   // (this lane's pixel pair) read before the next tile's statistics are requested
     __syncthreads();
     if (active) issue_dy(tile, 1);
     // ---- tile i-1: LayerNorm backward, transpose through its dres tile, store dx
