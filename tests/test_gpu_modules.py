@@ -371,14 +371,18 @@ def test_block_fp32_elementwise_relative(c, heads, shape):
         elementwise(v, ps[k].grad, "g_" + k)
 
 
-def test_training_steps_follow_the_oracle_trajectory():
-    """Three whole training steps of Restormer-tiny (forward, L1, backward, AdamW) on the GPU through FlatTrainer - native kernels,
-    main_grad accumulation into the flat buffer, the fused AdamW kernel - against the CPU oracle driven by torch autograd and
-    torch.optim.AdamW (MoCE-IR-main/src/train.py:50-88: L1Loss + AdamW(lr 2e-4)): the loss of every step within 1e-4, every
-    parameter after the last step within 2e-3 of the largest value (fp32 activations: the parity path)."""
+@pytest.mark.parametrize("name,dtype,ltol,ptol", [("tiny", torch.float32, 1e-4, 2e-3), ("dim48", torch.bfloat16, 2e-2, None)])
+def test_training_steps_follow_the_oracle_trajectory(name, dtype, ltol, ptol):
+    """Three whole training steps (forward, L1, backward, AdamW) on the GPU through FlatTrainer - native kernels, main_grad
+    accumulation into the flat buffer, the fused AdamW kernel - against the CPU oracle driven by torch autograd and
+    torch.optim.AdamW (MoCE-IR-main/src/train.py:50-88: L1Loss + AdamW): the loss of every step and every parameter after the
+    last step.  fp32 activations (Restormer-tiny): 1e-4 / 2e-3 of the largest value.  bf16 activations at the real block widths
+    (dim 48, one block per level: the LayerNorm-in-GEMM head and the one-launch backward tails run at C = 48 and 96): losses to 2e-2,
+    parameters in units of the learning rate - the first AdamW steps move every weight by ~lr whatever the gradient's size, so a
+    bf16-flipped sign of a tiny gradient shows up as 2 lr per step on that weight (bound: 6.3 lr worst case, 0.4 lr on average; measured up to 5.8 and 0.27)."""
     m = M()
     from image_restoration_amd.trainer import FlatTrainer
-    cfg = R.RESTORMER_TINY
+    cfg = R.RESTORMER_TINY if name == "tiny" else R.restormer_config(dim=48, num_blocks=(1, 1, 1, 1), num_refinement_blocks=1)
     sd0 = R.make_restormer_state(cfg, seed=2)
     clean = torch.from_numpy(np.random.default_rng(77).random((2, 3, 64, 64))).to(torch.float32)
     noisy = R.degrade_sigma(clean, 25.0, seed=78)
@@ -399,17 +403,23 @@ def test_training_steps_follow_the_oracle_trajectory():
     net = net.to(DEV).train()
     tr = FlatTrainer(net, lr=lr, weight_decay=0.01)
     try:
-        x, y = noisy.to(DEV), clean.to(DEV)
+        x, y = noisy.to(DEV).to(dtype), clean.to(DEV).to(dtype)
         for step in range(3):
             tr.zero_grad()
-            loss = (net(x) - y).abs().mean()
+            loss = (net(x).float() - y.float()).abs().mean()
             loss.backward()
             tr.reduce_gradients()
             tr.optimizer_step()
-            assert abs(float(loss) - ref_losses[step]) < 1e-4 * ref_losses[step], (step, float(loss), ref_losses[step])
+            assert abs(float(loss) - ref_losses[step]) < ltol * ref_losses[step], (step, float(loss), ref_losses[step])
         got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     finally:
         tr.close()
     assert ref_losses[2] < ref_losses[0]                       # the steps do reduce the loss
     for k, v in ps.items():
-        assert rel(got[k], v.detach()) < 2e-3, (k, rel(got[k], v.detach()))
+        if dtype == torch.float32:
+            assert rel(got[k], v.detach()) < ptol, (k, rel(got[k], v.detach()))
+        else:
+            # absolute, in units of lr: an AdamW step moves a weight by at most ~lr (bias-corrected m / sqrt(v) <= 1), so two runs
+            # that disagree on the sign of a tiny gradient in all three steps end 2 * 3 lr apart; most weights agree far better
+            d = (got[k].double() - v.detach().double()).abs()
+            assert float(d.max()) < 6.3 * lr and float(d.mean()) < 0.4 * lr, (k, float(d.max()) / lr, float(d.mean()) / lr)
