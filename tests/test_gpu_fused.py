@@ -338,3 +338,35 @@ def test_round2_switches_leave_the_block_unchanged(c, heads, shape, monkeypatch)
                 assert torch.equal(a, b), (env, i, float((a - b).abs().max()))
             else:
                 assert rel(a, b) < 2e-2, (env, i, rel(a, b))
+
+
+@pytest.mark.parametrize("c,heads,hw", [(96, 1, (256, 256)), (192, 4, (64, 64)), (384, 8, (32, 32))])
+def test_full_size_batch_is_consistent_with_a_small_one(c, heads, hw):
+    """BASELINE's full per-GPU batch (32) at the step's real planes, through a property that needs no oracle at that size: a batch
+    of 16 copies of image A and 16 of image B must give, per image, what a batch [A, B] gives (every kernel is per-image in the
+    forward and in the input gradient; the launch plans - pixel splits, tiles per wave, M splits, folded Grams - change with the
+    batch, so sums are taken in another order: equal to bf16 rounding, 1e-2 / 2e-2 of the largest value, and EXACTLY equal between
+    copies inside the big batch), and parameter gradients 16 times those of the small batch (2e-2).  The small batch itself is held to the oracle elsewhere."""
+    m = M()
+    H, W = hw
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=131 + c)
+    xs = seeded_input((2, c, H, W), 7300 + c)
+    cs = seeded_input((2, c, H, W), 7301 + c)
+
+    def run_block(x0, cot):
+        blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+        blk.load_state_dict(sd)
+        x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        y = blk(x)
+        y.backward(cot.to(DEV).to(torch.bfloat16))
+        return y.detach(), x.grad, {k: p.grad.float() for k, p in blk.named_parameters()}
+
+    ys, dxs, gs = run_block(xs, cs)
+    idx = torch.tensor([0] * 16 + [1] * 16)
+    yb, dxb, gb = run_block(xs[idx], cs[idx])
+    for i in (0, 7, 15, 16, 31):
+        assert rel(yb[i], ys[idx[i]].float()) < 1e-2, ("forward", i, rel(yb[i], ys[idx[i]].float()))
+        assert rel(dxb[i], dxs[idx[i]].float()) < 2e-2, ("input gradient", i, rel(dxb[i], dxs[idx[i]].float()))
+    assert torch.equal(yb[0], yb[15]) and torch.equal(yb[16], yb[31]) and torch.equal(dxb[0], dxb[15])   # copies inside one batch: exact
+    for k in gs:
+        assert rel(gb[k], 16.0 * gs[k]) < 2e-2, (k, rel(gb[k], 16.0 * gs[k]))
