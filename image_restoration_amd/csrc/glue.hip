@@ -54,9 +54,11 @@ template <int LPR> struct GUnit {
   }
 };
 
-template <typename T, int LPR>
+// (FLIP is a template parameter: as a run-time argument it made the window arrays dynamically indexed, the compiler put them in
+//  scratch memory - 96 bytes per lane - and the kernel ran at 1.95 TB/s)
+template <typename T, int LPR, bool FLIP>
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ out, int planes, int H, int W,
-                                                        int nb, int band_rows, int flip) {
+                                                        int nb, int band_rows) {
   using R = GRaw<T>;
   using RV = typename R::V;
   const GUnit<LPR> u(planes, nb, band_rows);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x,
     if (u.active && y < yend) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int src = flip ? 8 - tap : tap;
+        const int src = FLIP ? 8 - tap : tap;
         const int ky = src / 3, kx = src - 3 * ky;
         const float* r = ky == 0 ? w0 : (ky == 1 ? w1 : w2);
         float o[4] = {r[kx], r[kx + 1], r[kx + 2], r[kx + 3]};
@@ -230,11 +232,15 @@ extern "C" int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W
   const GPlan p = g_plan(H, W, planes);
   ProfScope ps(st, K_IM2COL, 10.0 * planes * H * W * dtype_size(dtype), 0.0);
   if (dtype == MI_F32) {
-    G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<float, LPR>), dim3(p.blocks), dim3(256), 0, st, (const float*)x, (float*)out,
-                                       (int)planes, H, W, p.nb, p.band, flip));
+    if (flip) { G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<float, LPR, true>), dim3(p.blocks), dim3(256), 0, st, (const float*)x,
+                                                   (float*)out, (int)planes, H, W, p.nb, p.band)); }
+    else { G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<float, LPR, false>), dim3(p.blocks), dim3(256), 0, st, (const float*)x,
+                                              (float*)out, (int)planes, H, W, p.nb, p.band)); }
   } else {
-    G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<bf16, LPR>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out,
-                                       (int)planes, H, W, p.nb, p.band, flip));
+    if (flip) { G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<bf16, LPR, true>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)x,
+                                                   (bf16*)out, (int)planes, H, W, p.nb, p.band)); }
+    else { G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<bf16, LPR, false>), dim3(p.blocks), dim3(256), 0, st, (const bf16*)x,
+                                              (bf16*)out, (int)planes, H, W, p.nb, p.band)); }
   }
   MI_LAUNCH_CHECK();
   return MI_OK;

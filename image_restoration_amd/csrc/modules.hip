@@ -442,7 +442,7 @@ extern "C" int mi_mdta_fwd_ln_ok(const mi_mdta_shape* s) {
 extern "C" int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const void* x,
                               const void* residual, void* out, void* saved, void* ws, void* stream) {
   MI_TRY(ln_head_check(ln, "mdta_fwd_ln"));
-  MI_CHECK_ARG(mi_mdta_fwd_ln_ok(s), "mdta_fwd_ln: shape not covered (bf16, C <= 192, H*W %% 64 == 0)");
+  MI_CHECK_ARG(mi_mdta_fwd_ln_ok(s), "mdta_fwd_ln: shape not covered (bf16, C <= 128, H*W %% 64 == 0)");
   return mdta_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
 }
 
@@ -629,7 +629,7 @@ extern "C" int mi_gdfn_fwd_ln_ok(const mi_gdfn_shape* s) {
 extern "C" int mi_gdfn_fwd_ln(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_head* ln, const void* x,
                               const void* residual, void* out, void* saved, void* ws, void* stream) {
   MI_TRY(ln_head_check(ln, "gdfn_fwd_ln"));
-  MI_CHECK_ARG(mi_gdfn_fwd_ln_ok(s), "gdfn_fwd_ln: shape not covered (bf16, C <= 192, H*W %% 64 == 0)");
+  MI_CHECK_ARG(mi_gdfn_fwd_ln_ok(s), "gdfn_fwd_ln: shape not covered (bf16, C <= 128, H*W %% 64 == 0)");
   return gdfn_fwd_impl(s, p, x, residual, out, saved, ws, stream, ln);
 }
 

@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
 // A 32-pixel-per-wave variant for K = 193 .. 384 (fragments still 96 VGPRs) was built, parity-tested and measured: no gain at the latent
 // level (1152 x 384 66 -> 71 us, 2042 x 384 122 -> 112 us) - each weight fragment read from LDS then feeds only 2 MFMAs - and was dropped.
 constexpr int PWX_SR = 64;   // output channels per staged weight slab (32 - two workgroups per CU by LDS, twice the barriers - measured 5-12 % slower)
-template <int KB, bool F8>
+template <int KB, bool F8, bool LN>   // LN: LayerNorm on load (a template parameter: as a run-time branch its registers spilled the plain path)
 __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, int n_slabs, int slabs_per_wg, int chunk_stride_elems) {
   using Op = PwwOp<F8>;
   Op::enter();
@@ -1070,9 +1070,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
       if (v < VPS) reinterpret_cast<u32x4*>(Wl + buf * SLAB)[v] = wr[i];
     }
   };
-  w_load(s0);
+  if constexpr (!LN) w_load(s0);                                     // (LN form: after the tile is normalised - its registers are needed there)
   float* const lnp = reinterpret_cast<float*>(Wl + 2 * SLAB + PWW_MW * PWW_PATCH);   // gamma | beta (LayerNorm on load)
-  if (q.ln_mode) {
+  if constexpr (LN) {
     for (int i = t; i < KB * PW_KC; i += NT) {
       lnp[i] = i < p.k1 ? q.ln_w[i] : 0.f;
       lnp[KB * PW_KC + i] = (i < p.k1 && q.ln_b) ? q.ln_b[i] : 0.f;
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
     for (int kb = 0; kb < KB; ++kb) {
       pww_load_chunk(raw[kb], x, kb, n0, lane);
     }
-    if (q.ln_mode)                                                   // LayerNorm over K while the tile sits in the load registers
+    if constexpr (LN)                                                // LayerNorm over K while the tile sits in the load registers
       pww_ln_inplace<KB>(raw, x.ktot, lnp, q.ln_mode, q.ln_mean ? q.ln_mean + zb * p.n + n0 : nullptr,
                          q.ln_rstd ? q.ln_rstd + zb * p.n + n0 : nullptr, lane);
 #pragma unroll
@@ -1111,6 +1111,7 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
       for (int nf = 0; nf < NF; ++nf) a[kb][nf] = Op::cvt(a16[nf], q.f8_sx);
     }
   }
+  if constexpr (LN) w_load(s0);
   w_store(0, s0);
   __syncthreads();
   for (int sl = s0; sl < s1; ++sl) {
@@ -1329,9 +1330,9 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     MI_CHECK_ARG(d->f8_sx > 0.f && d->f8_sw > 0.f, "pw_gemm: fp8 operand scales must be positive (powers of two)");
   }
   if (d->ln_mode) {
-    MI_CHECK_ARG((pl.wave == 1 || pl.wave == 3) && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
+    MI_CHECK_ARG((pl.wave == 1 || (pl.wave == 3 && pl.k_chunks <= 4)) && d->k2 == 0 && d->groups == 1 && d->ln_w && (d->ln_mode == 2 || d->ln_b) &&
                      (d->ln_mode == 1 || d->ln_mode == 2) && (d->ln_mean == nullptr) == (d->ln_rstd == nullptr),
-                 "pw_gemm: LayerNorm-on-load needs an X-resident form (bf16; 96 < M with K <= 96, or 256 <= M with K <= 192; one K panel, one group; "
+                 "pw_gemm: LayerNorm-on-load needs an X-resident form (bf16; 96 < M with K <= 96, or 256 <= M with K <= 128; one K panel, one group; "
                  "mi_pw_gemm_ln_ok)");
   }
   dim3 grid(cdiv(k.n, PW_TN), pl.m_tiles, d->batch * k.groups), block(256);
@@ -1383,12 +1384,14 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     hipLaunchKernelGGL(KERNEL, wgrid, wblock, lds, st, q, __VA_ARGS__);                                                      \
   } while (0)
       if (pl.wave == 3) {
-#define PWX_CASE(KB_)                                                                                                          \
+#define PWX_CASE(KB_, LNOK_)                                                                                                   \
   if (pl.k_chunks == KB_) {                                                                                                    \
-    if (d->f8) PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, true>), n_slabs, slabs_per, pl.chunk_elems);                         \
-    else PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, false>), n_slabs, slabs_per, pl.chunk_elems);                              \
+    if (LNOK_ && d->f8 && d->ln_mode) PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, true, LNOK_>), n_slabs, slabs_per, pl.chunk_elems);  \
+    else if (d->f8) PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, true, false>), n_slabs, slabs_per, pl.chunk_elems);             \
+    else if (LNOK_ && d->ln_mode) PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, false, LNOK_>), n_slabs, slabs_per, pl.chunk_elems);     \
+    else PWW_LAUNCH((pw_gemm_wave_xwide_kernel<KB_, false, false>), n_slabs, slabs_per, pl.chunk_elems);                       \
   }
-        PWX_CASE(4) else PWX_CASE(5) else PWX_CASE(6)
+        PWX_CASE(4, true) else PWX_CASE(5, false) else PWX_CASE(6, false)
 #undef PWX_CASE
       } else if (pl.wave == 1 && !d->f8) {
         if (pl.k_chunks == 1) PWW_LAUNCH((pw_gemm_wave_xres_kernel<1, false>), pl.m_tiles, (int)tpw, pl.chunk_elems);
@@ -1490,8 +1493,10 @@ extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
 
 extern "C" int mi_pw_gemm_ln_ok(const mi_pw_desc* d) {
   if (!d || pw_check(d) != MI_OK || d->k2 != 0 || d->groups != 1) return 0;
-  const int w = pw_plan(d).wave;
-  return (w == 1 || w == 3) ? 1 : 0;     // the two X-resident forms
+  // the two X-resident forms; the W-streamed one up to K = 128 only: at K = 129 .. 192 the tile (96 load registers) plus the
+  // statistics spill (60 / 252 bytes of scratch per lane) and the separate LayerNorm kernel is the better choice
+  const PwPlan pl = pw_plan(d);
+  return (pl.wave == 1 || (pl.wave == 3 && pl.k_chunks <= 4)) ? 1 : 0;
 }
 
 extern "C" int mi_pw_gemm_split_ok(const mi_pw_desc* d) {

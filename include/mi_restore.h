@@ -112,7 +112,7 @@ typedef struct {
   /* Optional LayerNorm over the K channels of X1, applied as the tile is loaded (Restormer.py:27-70 in front of :89 / :115):
    * ln_mode 0 = none, 1 = WithBias ((x - mu) rstd w + b), 2 = BiasFree (x rstd w); ln_w / ln_b [K]; ln_mean / ln_rstd
    * [batch, n] receive the statistics (both or neither).  Only where mi_pw_gemm_ln_ok() says so (the X-resident kernels:
-   * bf16; 96 < M with K <= 96, or 256 <= M with K <= 192; one K panel, one group); zero-initialise the struct to leave it off. */
+   * bf16; 96 < M with K <= 96, or 256 <= M with K <= 128; one K panel, one group); zero-initialise the struct to leave it off. */
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;
   /* Optional fp8 (OCP e4m3) MFMA operands - the "CDNA4 fp8 MFMA projections" of the tiled-inference configuration (BASELINE
    * configs[4]); inference only.  f8 = 1: X (after the optional LayerNorm) is divided by f8_sx and W (its packed bf16 image)
@@ -282,7 +282,7 @@ typedef struct {
 } mi_ln_tail;
 /* LayerNorm in front of the half-block's first 1x1 conv, applied inside that GEMM (the normalised tensor never reaches HBM):
  * mi_mdta_fwd_ln / mi_gdfn_fwd_ln = mi_mdta_fwd / mi_gdfn_fwd with x the LayerNorm INPUT.  mean / rstd [B, H*W] receive the
- * statistics for the backward pass (both or neither).  Shapes: mi_*_fwd_ln_ok (bf16, C <= 192, H*W a multiple of 64). */
+ * statistics for the backward pass (both or neither).  Shapes: mi_*_fwd_ln_ok (bf16, C <= 128, H*W a multiple of 64). */
 typedef struct { const float* w; const float* b; float* mean; float* rstd; int with_bias; } mi_ln_head;
 int mi_mdta_fwd_ln_ok(const mi_mdta_shape* s);
 int mi_mdta_fwd_ln(const mi_mdta_shape* s, const mi_mdta_params* p, const mi_ln_head* ln, const void* x, const void* residual,

@@ -272,7 +272,7 @@ def test_block_backward_with_and_without_tail(c, heads, shape, monkeypatch):
 # ------------------------------------------------------------------------------------------------ LayerNorm inside the first 1x1 conv
 @pytest.mark.parametrize("kind", ["WithBias", "BiasFree"])
 @pytest.mark.parametrize("c,heads,f,shape", [(48, 1, 2.66, (2, 48, 16, 64)), (96, 2, 2.66, (2, 96, 8, 64)), (64, 2, 2.0, (1, 64, 16, 32)),
-                                             (192, 4, 2.66, (2, 192, 8, 72)), (160, 2, 2.0, (1, 160, 16, 64))])   # K > 96: the W-streamed form
+                                             (128, 4, 2.66, (2, 128, 8, 72)), (112, 2, 2.5, (1, 112, 16, 64))])   # 96 < K <= 128: the W-streamed form
 def test_ln_head_inside_first_gemm(c, heads, f, shape, kind):
     """mi_mdta_fwd_ln / mi_gdfn_fwd_ln (LayerNorm applied as the GEMM loads its tile) against ln_fwd followed by the plain entry
     points: same arithmetic, so the two agree to a few bf16 ulps (5e-3 of the largest magnitude; the summation order of the
@@ -302,7 +302,7 @@ def test_ln_head_inside_first_gemm(c, heads, f, shape, kind):
 
 def test_ln_head_rejects_uncovered_shapes():
     from image_restoration_amd import ops
-    assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 384, 16, 64), dtype=torch.bfloat16, device=DEV), 8, 3)   # K > 192
+    assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 192, 16, 64), dtype=torch.bfloat16, device=DEV), 4, 3)   # K > 128
     assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 16, 64), dtype=torch.float32, device=DEV), 1, 3)     # fp32
     assert not ops.mdta_fwd_ln_ok(torch.zeros((1, 48, 10, 10), dtype=torch.bfloat16, device=DEV), 1, 3)    # ragged plane
 
