@@ -23,32 +23,33 @@ struct GramK {
   int fold;        // > 0: the batch is folded into the pixel axis (weight gradients): chunk / step c lies in image c / fold
 };
 
-template <typename T, int F, bool SS>
+template <typename T, int FA, int FB, bool SS>   // tile = (32 FA) rows of A x (32 FB) rows of B; the 2 x 2 waves own 16 FA x 16 FB fragments each
 __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   constexpr bool F32 = std::is_same<T, float>::value;
-  constexpr int TA = 32 * F;               // tile rows (A) == tile cols (B)
+  constexpr int TA = 32 * FA, TB = 32 * FB;
   constexpr int KC = F32 ? 32 : 64;        // pixels per staged chunk (128 bytes per row)
   constexpr int AS = F32 ? 34 : 72;        // LDS row stride, elements
   constexpr int EPV = F32 ? 4 : 8;         // elements per 16-byte vector
   __shared__ __attribute__((aligned(16))) T As[TA * AS];
-  __shared__ __attribute__((aligned(16))) T Bs[TA * AS];
+  __shared__ __attribute__((aligned(16))) T Bs[TB * AS];
 
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar wave index)
   const int li = lane & 15, g = lane >> 4;
   const int wr = wv >> 1, wc = wv & 1;
   const int z = blockIdx.z, zb = p.fold ? 0 : z / p.groups, zg = p.fold ? z : z - zb * p.groups;
   const int ta = blockIdx.y / p.tiles_b, tb = blockIdx.y - ta * p.tiles_b;
-  const int i0 = ta * TA, j0 = tb * TA;
+  const int i0 = ta * TA, j0 = tb * TB;
   const T* A = (const T*)p.a + zb * p.a_bs + zg * p.a_gs;
   const T* B = (const T*)p.b + zb * p.b_bs + zg * p.b_gs;
   const int c_begin = blockIdx.x * p.chunks_per_split;
   int c_end = c_begin + p.chunks_per_split;
   if (c_end > p.nchunks) c_end = p.nchunks;
 
-  u32x4 areg[F], breg[F];
+  u32x4 areg[FA], breg[FB];
   // (thread / lane ids below are opaque copies: the per-lane address terms are loop-invariant, and kept across the chunk loop
   //  they are what lifts this kernel over the 170 registers that allow a third workgroup per CU)
-  auto load_rows = [&](const T* base, int64_t img_stride, int row0, int rows, int chunk, u32x4* regs) {
+  auto load_rows = [&](auto cnt, const T* base, int64_t img_stride, int row0, int rows, int chunk, u32x4* regs) {
+    constexpr int F = decltype(cnt)::value;
     int tt = t;
     asm volatile("" : "+v"(tt));
     if (p.fold) {                                                    // (uniform) image of this chunk, chunk inside the image
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
       }
     }
   };
-  auto write_rows = [&](T* dst, const u32x4* regs) {
+  auto write_rows = [&](auto cnt, T* dst, const u32x4* regs) {
+    constexpr int F = decltype(cnt)::value;
     int tt = t;
     asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -89,44 +91,52 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
     }
   };
 
-  f32x4 acc[F][F];
-  float ssa[F], ssb[F];
+  constexpr std::integral_constant<int, FA> NA{};
+  constexpr std::integral_constant<int, FB> NB{};
+  f32x4 acc[FA][FB];
+  float ssa[FA], ssb[FB];
 #pragma unroll
-  for (int a = 0; a < F; ++a) {
-    ssa[a] = 0.f; ssb[a] = 0.f;
+  for (int a = 0; a < FA; ++a) {
+    ssa[a] = 0.f;
 #pragma unroll
-    for (int b = 0; b < F; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int ra = wr * 16 * F, cb = wc * 16 * F;  // wave's first row / col inside the tile
+#pragma unroll
+  for (int b = 0; b < FB; ++b) ssb[b] = 0.f;
+  const int ra = wr * 16 * FA, cb = wc * 16 * FB;  // wave's first row / col inside the tile
 
   if (c_begin < c_end) {
-    load_rows(A, p.a_bs, i0, p.ma, c_begin, areg);
-    load_rows(B, p.b_bs, j0, p.mb, c_begin, breg);
+    load_rows(NA, A, p.a_bs, i0, p.ma, c_begin, areg);
+    load_rows(NB, B, p.b_bs, j0, p.mb, c_begin, breg);
   }
   for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();
-    write_rows(As, areg);
-    write_rows(Bs, breg);
+    write_rows(NA, As, areg);
+    write_rows(NB, Bs, breg);
     __syncthreads();
     if (c + 1 < c_end) {
-      load_rows(A, p.a_bs, i0, p.ma, c + 1, areg);
-      load_rows(B, p.b_bs, j0, p.mb, c + 1, breg);
+      load_rows(NA, A, p.a_bs, i0, p.ma, c + 1, areg);
+      load_rows(NB, B, p.b_bs, j0, p.mb, c + 1, breg);
     }
     if constexpr (F32) {
 #pragma unroll
       for (int ks = 0; ks < KC / 4; ++ks) {
         const int kk = 4 * ks + g;
-        float av[F], bv[F];
+        float av[FA], bv[FB];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
+        for (int f = 0; f < FA; ++f) {
           av[f] = As[(ra + 16 * f + li) * AS + kk];
-          bv[f] = Bs[(cb + 16 * f + li) * AS + kk];
-          if (SS) { ssa[f] += av[f] * av[f]; ssb[f] += bv[f] * bv[f]; }
+          if (SS) ssa[f] += av[f] * av[f];
         }
 #pragma unroll
-        for (int fa = 0; fa < F; ++fa)
+        for (int f = 0; f < FB; ++f) {
+          bv[f] = Bs[(cb + 16 * f + li) * AS + kk];
+          if (SS) ssb[f] += bv[f] * bv[f];
+        }
 #pragma unroll
-          for (int fb = 0; fb < F; ++fb)
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb)
             acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
       }
     } else {
@@ -136,24 +146,33 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
       const T* bp = &Bs[(cb + (ln & 15)) * AS + 8 * (ln >> 4)];
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
-        s16x8 av[F], bv[F];
+        s16x8 av[FA], bv[FB];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
+        for (int f = 0; f < FA; ++f) {
           av[f] = *reinterpret_cast<const s16x8*>(ap + 16 * f * AS + 32 * ks);
-          bv[f] = *reinterpret_cast<const s16x8*>(bp + 16 * f * AS + 32 * ks);
           if (SS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float x = bf16_bits_to_f32((unsigned int)(unsigned short)av[f][e]);
-              const float y = bf16_bits_to_f32((unsigned int)(unsigned short)bv[f][e]);
-              ssa[f] += x * x; ssb[f] += y * y;
+              ssa[f] += x * x;
             }
           }
         }
 #pragma unroll
-        for (int fa = 0; fa < F; ++fa)
+        for (int f = 0; f < FB; ++f) {
+          bv[f] = *reinterpret_cast<const s16x8*>(bp + 16 * f * AS + 32 * ks);
+          if (SS) {
 #pragma unroll
-          for (int fb = 0; fb < F; ++fb)
+            for (int e = 0; e < 8; ++e) {
+              const float y = bf16_bits_to_f32((unsigned int)(unsigned short)bv[f][e]);
+              ssb[f] += y * y;
+            }
+          }
+        }
+#pragma unroll
+        for (int fa = 0; fa < FA; ++fa)
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb)
             acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[fa], bv[fb], acc[fa][fb], 0, 0, 0);
       }
     }
@@ -162,9 +181,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   // lane holds G[i0+ra+16fa+4g+r][j0+cb+16fb+li]
   float* pz = p.part + ((int64_t)blockIdx.x * p.Z + z) * ((int64_t)p.ma * p.mb);
 #pragma unroll
-  for (int fa = 0; fa < F; ++fa)
+  for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
-    for (int fb = 0; fb < F; ++fb) {
+    for (int fb = 0; fb < FB; ++fb) {
       const int j = j0 + cb + 16 * fb + li;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -175,15 +194,18 @@ __global__ __launch_bounds__(256) void gram_kernel(GramK p) {
   if (SS && p.ss_part) {
     float* sz = p.ss_part + ((int64_t)blockIdx.x * p.Z + z) * (p.ma + p.mb);
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      float sa = ssa[f], sb = ssb[f];
+    for (int f = 0; f < FA; ++f) {
+      float sa = ssa[f];
       sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+      const int i = i0 + ra + 16 * f + li;
+      if (g == 0 && wc == 0 && tb == 0 && i < p.ma) sz[i] = sa;
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      float sb = ssb[f];
       sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-      if (g == 0) {
-        const int i = i0 + ra + 16 * f + li, j = j0 + cb + 16 * f + li;
-        if (wc == 0 && tb == 0 && i < p.ma) sz[i] = sa;
-        if (wr == 0 && ta == 0 && j < p.mb) sz[p.ma + j] = sb;
-      }
+      const int j = j0 + cb + 16 * f + li;
+      if (g == 0 && wr == 0 && ta == 0 && j < p.mb) sz[p.ma + j] = sb;
     }
   }
 }
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
-struct GramPlan { int F, kc, nchunks, tiles_a, tiles_b, splits, cps, Z, fold; size_t part_bytes, ss_bytes; };
+struct GramPlan { int FA, FB, kc, nchunks, tiles_a, tiles_b, splits, cps, Z, fold; size_t part_bytes, ss_bytes; };
 
 // Weight gradients sum over the batch: instead of one partial tile per image (and a reduction over batch x splits partials),
 // the images are chained along the contraction axis - a workgroup's pixel range may cross image boundaries - whenever an image
@@ -425,12 +447,23 @@ static int gram_want(int dflt) {
 
 static GramPlan gram_plan(const mi_gram_desc* d) {
   GramPlan g;
-  g.F = (d->ma > 64 || d->mb > 64) ? 4 : 2;
-  const int tile = 32 * g.F;
+  g.FA = g.FB = (d->ma > 64 || d->mb > 64) ? 4 : 2;
+  // rectangular tiles (bf16): a tile that holds ALL of the shorter operand's rows reads the other operand once instead of once
+  // per 128-row tile of it - 96 x 255 (project_out's weight gradient) as ONE 96 x 256 tile, M x 192 (the C = 192 level) and the
+  // wide M x 384 as 128 x 192 tiles.  bs 32 (profiles/r02_o_gram_rect_tiles.txt): 96 x 255 at 256^2 343 -> 304 us, 1020 x 192
+  // 158 -> 116, 576 x 192 124 -> 85, 2042 x 384 128 -> 105 (384 x 384 loses: 35 -> 39, stays square); step 153.6 -> 152.1 ms.
+  // MI_GRAM_RECT=0: square tiles only (A/B switch).
+  {
+    const char* e = getenv("MI_GRAM_RECT");
+    if (d->dtype == MI_BF16 && !d->sumsq && !(e && e[0] == '0')) {
+      if (d->ma <= 96 && d->mb > 128 && d->mb <= 256) { g.FA = 3; g.FB = 8; }
+      else if (d->ma > 128 && d->mb > 128 && (d->mb <= 192 || (d->mb == 384 && d->ma > 384))) { g.FA = 4; g.FB = 6; }
+    }
+  }
   g.kc = d->dtype == MI_BF16 ? 64 : 32;
   g.nchunks = cdiv(d->n, g.kc);
-  g.tiles_a = cdiv(d->ma, tile);
-  g.tiles_b = cdiv(d->mb, tile);
+  g.tiles_a = cdiv(d->ma, 32 * g.FA);
+  g.tiles_b = cdiv(d->mb, 32 * g.FB);
   g.fold = gram_fold(d, g.kc, (int64_t)g.tiles_a * g.tiles_b * d->groups);
   if (g.fold) g.nchunks = d->batch * g.fold;
   g.Z = (g.fold ? 1 : d->batch) * d->groups;
@@ -591,13 +624,15 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   const double ZZ = (double)d->batch * d->groups;
   ProfScope ps(st, d->sumsq ? K_GRAM_QK : K_GRAM, (double)(d->ma + d->mb) * d->n * ZZ * es + 4.0 * g.splits * g.Z * d->ma * d->mb,
                2.0 * d->ma * d->mb * (double)d->n * ZZ);
-#define GRAM_CASE(T, F)                                                                     \
-  do {                                                                                      \
-    if (ss) hipLaunchKernelGGL((gram_kernel<T, F, true>), grid, block, 0, st, k);           \
-    else hipLaunchKernelGGL((gram_kernel<T, F, false>), grid, block, 0, st, k);             \
+#define GRAM_CASE(T, FA_, FB_)                                                                      \
+  do {                                                                                              \
+    if (ss) hipLaunchKernelGGL((gram_kernel<T, FA_, FB_, true>), grid, block, 0, st, k);            \
+    else hipLaunchKernelGGL((gram_kernel<T, FA_, FB_, false>), grid, block, 0, st, k);              \
   } while (0)
-  if (d->dtype == MI_F32) { if (g.F == 4) GRAM_CASE(float, 4); else GRAM_CASE(float, 2); }
-  else { if (g.F == 4) GRAM_CASE(bf16, 4); else GRAM_CASE(bf16, 2); }
+  if (d->dtype == MI_F32) { if (g.FA == 4) GRAM_CASE(float, 4, 4); else GRAM_CASE(float, 2, 2); }
+  else if (g.FA == 3 && g.FB == 8) GRAM_CASE(bf16, 3, 8);
+  else if (g.FA == 4 && g.FB == 6) GRAM_CASE(bf16, 4, 6);
+  else { if (g.FA == 4) GRAM_CASE(bf16, 4, 4); else GRAM_CASE(bf16, 2, 2); }
 #undef GRAM_CASE
   }
   MI_LAUNCH_CHECK();

@@ -216,7 +216,8 @@ def test_gram_long_reduction_random(dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("ma,mb,B,hw", [(48, 48, 4, (16, 64)), (144, 48, 5, (16, 64)), (576, 192, 3, (16, 64)), (300, 200, 2, (8, 64)),
-                                        (96, 255, 32, (4, 64)), (130, 70, 3, (24, 64))])
+                                        (96, 255, 32, (4, 64)), (130, 70, 3, (24, 64)), (1020, 192, 2, (16, 64)), (90, 250, 2, (8, 72)),
+                                        (700, 384, 2, (8, 64))])
 def test_gram_batch_fold_exact_on_integers(monkeypatch, dtype, ma, mb, B, hw):
     """Weight-gradient Grams (sum over the batch) with the images chained along the contraction axis: workgroup pixel ranges that
     cross image boundaries, both kernels (LDS-staged and streaming), against the per-image form and the host.  MI_GRAM_FOLD: 0 =
@@ -232,6 +233,10 @@ def test_gram_batch_fold_exact_on_integers(monkeypatch, dtype, ma, mb, B, hw):
             monkeypatch.setenv("MI_GRAM_FOLD", mode)
         out = o.gram(a.to(DEV), b.to(DEV), 1, True)
         assert torch.equal(out.cpu(), ref), (mode, float((out.cpu() - ref).abs().max()))
+        monkeypatch.setenv("MI_GRAM_RECT", "0")                 # square 128 x 128 tiles instead of 96 x 256 / 128 x 192
+        out = o.gram(a.to(DEV), b.to(DEV), 1, True)
+        monkeypatch.delenv("MI_GRAM_RECT")
+        assert torch.equal(out.cpu(), ref), ("square", mode)
         monkeypatch.setenv("MI_GRAM_STREAM_ALL", "1")
         out = o.gram(a.to(DEV), b.to(DEV), 1, True)
         monkeypatch.delenv("MI_GRAM_STREAM_ALL")
