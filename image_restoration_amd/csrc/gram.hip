@@ -455,7 +455,9 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
   // MI_GRAM_RECT=0: square tiles only (A/B switch).
   {
     const char* e = getenv("MI_GRAM_RECT");
-    if (d->dtype == MI_BF16 && !d->sumsq && !(e && e[0] == '0')) {
+    if (d->dtype == MI_BF16 && !(e && e[0] == '0') && d->ma > 64 && d->ma <= 96 && d->mb > 64 && d->mb <= 96) {
+      g.FA = g.FB = 3;                                               // 96 x 96 (q k^T and dM at c = 96): no padded fragments
+    } else if (d->dtype == MI_BF16 && !d->sumsq && !(e && e[0] == '0')) {
       if (d->ma <= 96 && d->mb > 128 && d->mb <= 256) { g.FA = 3; g.FB = 8; }
       else if (d->ma > 128 && d->mb > 128 && (d->mb <= 192 || (d->mb == 384 && d->ma > 384))) { g.FA = 4; g.FB = 6; }
     }
@@ -530,7 +532,8 @@ static bool gram_stream_ok(const mi_gram_desc* d) {
   if (g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4) return true;
   // ... and where the 128 x 128 LDS tiles would be mostly padding (288 x 96 fills 56% of 3 x 1 tiles: streaming 1.27x
   // faster at bs 32; 96 x 255 and 510 x 96 fill 75% and stay on the LDS kernel; profiles/r01_y_gram_bs32.log)
-  const double lds_fill = (double)d->ma * d->mb / ((double)cdiv(d->ma, 128) * 128 * cdiv(d->mb, 128) * 128);
+  const GramPlan lp = gram_plan(d);                                  // (the tile the LDS kernel would actually use)
+  const double lds_fill = (double)d->ma * d->mb / ((double)lp.tiles_a * 32 * lp.FA * lp.tiles_b * 32 * lp.FB);
   return (d->ma > 64 || d->mb > 64) && lds_fill < 0.6;
 }
 
@@ -630,6 +633,7 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
     else hipLaunchKernelGGL((gram_kernel<T, FA_, FB_, false>), grid, block, 0, st, k);              \
   } while (0)
   if (d->dtype == MI_F32) { if (g.FA == 4) GRAM_CASE(float, 4, 4); else GRAM_CASE(float, 2, 2); }
+  else if (g.FA == 3 && g.FB == 3) GRAM_CASE(bf16, 3, 3);
   else if (g.FA == 3 && g.FB == 8) GRAM_CASE(bf16, 3, 8);
   else if (g.FA == 4 && g.FB == 6) GRAM_CASE(bf16, 4, 6);
   else { if (g.FA == 4) GRAM_CASE(bf16, 4, 4); else GRAM_CASE(bf16, 2, 2); }
