@@ -217,7 +217,7 @@ def test_gram_long_reduction_random(dtype):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("ma,mb,B,hw", [(48, 48, 4, (16, 64)), (144, 48, 5, (16, 64)), (576, 192, 3, (16, 64)), (300, 200, 2, (8, 64)),
                                         (96, 255, 32, (4, 64)), (130, 70, 3, (24, 64)), (1020, 192, 2, (16, 64)), (90, 250, 2, (8, 72)),
-                                        (700, 384, 2, (8, 64))])
+                                        (700, 384, 2, (8, 64)), (192, 510, 2, (8, 64)), (384, 1021, 2, (4, 64)), (150, 300, 3, (8, 72))])
 def test_gram_batch_fold_exact_on_integers(monkeypatch, dtype, ma, mb, B, hw):
     """Weight-gradient Grams (sum over the batch) with the images chained along the contraction axis: workgroup pixel ranges that
     cross image boundaries, both kernels (LDS-staged and streaming), against the per-image form and the host.  MI_GRAM_FOLD: 0 =
