@@ -24,8 +24,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   fp32_line        : a short run of the same step with fp32 activations (the exact-MFMA parity path, the reference's
                      mainline precision), reported beside the bf16 headline, never instead of it;
   cpu_baseline     : the CPU oracle (oracle/restormer_ref.py, "port") timed on this box's host cores: warm-up + median of
-                     3, forward and forward+backward, at all cores, 16 and 8 threads (value = the fastest), on a 128x128 patch: the
-                     whole leg stays within ~40 s (rank 0 at N=1 only).
+                     3 of forward + L1 + backward on one 1x3x256x256 patch (SURVEY 8(d)) at the thread count a 128x128 sweep picks;
+                     the whole leg stays within ~30 s (rank 0 at N=1 only).
 """
 from __future__ import annotations
 
@@ -111,46 +111,57 @@ def pmc_traffic(kernel: str):
     return (round(tot / n) if n else None), meta.get("commit")
 
 
-def cpu_baseline(patch: int = 128):
-    """Oracle training step on one patch, fp32: warm-up + median of 3, forward and forward+backward, all cores, 16 and 8 threads; value = the fastest."""
+def cpu_baseline():
+    """The CPU oracle's training step, fp32, on this box's host cores (SURVEY 8(d) / BASELINE.md s.3: 1 x 3 x 256^2).
+    A thread sweep on a 128^2 patch (forward at all cores / 16 / 8 threads, forward + backward at 16 / 8: oneDNN's small
+    convolutions do not scale to a whole socket) picks the thread count; the quoted value is forward + L1 + backward on ONE
+    256 x 256 patch at that setting, warm-up + median of 3, with the forward-only rate beside it.  ~30 s in all."""
     from image_restoration_amd.configs import RESTORMER_BASE as cfg
     from oracle import restormer_ref as R
     sd = {k: v.requires_grad_(True) for k, v in R.make_restormer_state(cfg, seed=0).items()}
-    g = torch.Generator().manual_seed(1234)
-    clean = torch.rand((1, 3, patch, patch), generator=g)
-    noisy = R.degrade_sigma(clean, 25.0, seed=4321)
 
-    def fwd():
+    def data(patch):
+        g = torch.Generator().manual_seed(1234)
+        clean = torch.rand((1, 3, patch, patch), generator=g)
+        return clean, R.degrade_sigma(clean, 25.0, seed=4321)
+
+    def fwd(clean, noisy):
         with torch.no_grad():
             return R.restormer_forward(noisy, sd, cfg)
 
-    def train():
+    def train(clean, noisy):
         for v in sd.values():
             v.grad = None
         (R.restormer_forward(noisy, sd, cfg) - clean).abs().mean().backward()
 
-    def med(fn, n=3):
-        fn()                                            # warm-up
+    def med(fn, args, n=3):
+        fn(*args)                                       # warm-up
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
-            fn()
+            fn(*args)
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
     allc = min(os.cpu_count() or 1, 64)
-    res = {}
     t_start = time.perf_counter()
+    small = data(128)
+    sweep = {}
     for threads in sorted({allc, 16, 8}, reverse=True):
         torch.set_num_threads(threads)
-        res[threads] = {"fwd_s": med(fwd), "train_s": med(train)}
-    px = patch * patch / 1e6
-    # value = the best thread setting (a box's GPU share of host cores is below os.cpu_count(): oversubscribed runs are slower)
-    best = min(res, key=lambda t: res[t]["train_s"])
-    return {"value": round(px / res[best]["train_s"], 6), "unit": "Mpixels/s", "cores": best, "kind": "port",
-            "sample": f"oracle.restormer_forward (+ L1 + backward), 1x3x{patch}x{patch} fp32, warm-up + median of 3; "
-                      f"whole leg {time.perf_counter() - t_start:.1f} s",
-            "train_mpix_s": {str(t): round(px / r["train_s"], 6) for t, r in res.items()},
-            "fwd_mpix_s": {str(t): round(px / r["fwd_s"], 6) for t, r in res.items()}}
+        sweep[threads] = {"fwd_s": med(fwd, small)}
+        if threads <= 16:
+            sweep[threads]["train_s"] = med(train, small)
+    best = min((t for t in sweep if "train_s" in sweep[t]), key=lambda t: sweep[t]["train_s"])
+    torch.set_num_threads(best)
+    big = data(256)
+    fwd256, train256 = med(fwd, big), med(train, big)
+    px128, px256 = 128 * 128 / 1e6, 256 * 256 / 1e6
+    return {"value": round(px256 / train256, 6), "unit": "Mpixels/s", "cores": best, "kind": "port",
+            "sample": f"oracle.restormer_forward + L1 + backward (Restormer base, fp32) on one 1x3x256x256 patch, {best} threads, "
+                      f"warm-up + median of 3; thread count picked by a 128x128 sweep; whole leg {time.perf_counter() - t_start:.1f} s",
+            "fwd_mpix_s_256": round(px256 / fwd256, 6),
+            "sweep_128": {"train_mpix_s": {str(t): round(px128 / r["train_s"], 6) for t, r in sweep.items() if "train_s" in r},
+                          "fwd_mpix_s": {str(t): round(px128 / r["fwd_s"], 6) for t, r in sweep.items()}}}
 
 
 def main():
@@ -300,13 +311,18 @@ def main():
         mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
         # the bound is whichever roof the kernel's algorithmic intensity puts nearer
         use_mfma = name in ("pw_gemm", "gram", "mdta_qk", "mdta_av") and (tfs / mfma_peak) > (gbs / HBM_PEAK_GBS)
-        traffic, traffic_commit = pmc_traffic(name)
+        # PMC traffic exists for the headline workload only (Restormer base, bs 32, 256^2, bf16: tools/profile_bench.sh);
+        # any other workload reports null rather than another workload's bytes
+        headline = args.model == "restormer" and batch == 32 and patch == 256 and args.dtype == "bf16"
+        traffic, traffic_commit = pmc_traffic(name) if headline else (None, None)
         roofline = {
             "kernel": name, "bound": "mfma" if use_mfma else "hbm",
             "achieved": round(tfs if use_mfma else gbs, 2), "peak": mfma_peak if use_mfma else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if use_mfma else "GB/s",
             "frac": round((tfs / mfma_peak) if use_mfma else (gbs / HBM_PEAK_GBS), 4),
-            "traffic": traffic, "traffic_source": f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command at commit {traffic_commit})",
+            "traffic": traffic,
+            "traffic_source": (f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command at commit {traffic_commit})" if traffic
+                               else "none: no PMC pass committed for this workload"),
             "launches_per_step": dom["launches"] // nprof,
             "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "alg_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
@@ -314,7 +330,7 @@ def main():
             "share_of_kernel_time": round(dom["ms"] / tot_ms, 4),
             "kernel_ms_per_step": round(tot_ms / nprof, 3),
         }
-        if not moce:
+        if args.model == "restormer":
             es = 2 if args.dtype == "bf16" else 4
             flops = 3.0 * configs.RESTORMER_BASE_FWD_FLOP_PER_PIXEL * (pixels_per_step / world)
             fused_bytes = 3.0 * configs.RESTORMER_BASE_FWD_FUSED_BYTES_PER_PIXEL_BF16 * (es / 2) * (pixels_per_step / world)
@@ -364,7 +380,7 @@ def main():
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(128)
+        cpu = cpu_baseline()
 
     if rank == 0:
         if moce:

@@ -6,8 +6,9 @@ through ``libmi_restore.so`` (``include/mi_restore.h``).  There is no CPU fallba
 on a CPU tensor, or without the built library, raises.
 """
 from . import _lib  # noqa: F401
+from .ops import reload_env  # noqa: F401
 from .restormer import (Attention, Downsample, FeedForward, LayerNorm, OverlapPatchEmbed, Restormer,  # noqa: F401
                         TransformerBlock, Upsample)
 
 __all__ = ["Attention", "Downsample", "FeedForward", "LayerNorm", "OverlapPatchEmbed", "Restormer",
-           "TransformerBlock", "Upsample"]
+           "TransformerBlock", "Upsample", "reload_env"]

@@ -103,6 +103,7 @@ class GdfnGrads(C.Structure):
 SIGNATURES = {
     "mi_version": (C.c_int, []),
     "mi_last_error": (C.c_char_p, []),
+    "mi_env_reload": (C.c_int, []),
     "mi_ln_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "mi_ln_bwd_workspace": (C.c_size_t, [C.c_int, C.c_int, c_i64]),
     "mi_ln_bwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,

@@ -27,6 +27,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "internal.h"
 #include "fused_common.h"
 
@@ -461,7 +463,7 @@ bool bwd_tail_ok(int M, int C, int64_t N, int dtype) {
 bool bwd_tail_pays(int M, int C) {
   BtPlan p;
   if (!bt_plan(M, C, &p)) return false;
-  const char* e = getenv("MI_BT_WIDE");                                 // A/B switch, read per call: 0 keeps the 4-fragment form off
+  const char* e = MI_ENV(MI_BT_WIDE);                                 // A/B switch, read per call: 0 keeps the 4-fragment form off
   return !(C == 96 && p.MPW == 4) || !(e && atoi(e) == 0);
 }
 // partial [G | S] per workgroup, its sum, and the two-stage row reduction's scratch
@@ -475,11 +477,16 @@ size_t bwd_tail_workspace(int M, int C) {
 template <int C, int NW, int MPW>
 static int bt_launch(const BtArgs& a, int grid, hipStream_t st) {
   using K = BtCfg<C, NW, MPW>;
-  static bool attr_set = false;   // raising the dynamic-LDS limit is a per-function, per-process setting
-  if (!attr_set) {
+  // raising the dynamic-LDS limit is a per-function, per-DEVICE setting: remembered per device (one process may drive several
+  // GPUs), not per process
+  static std::atomic<unsigned> attr_set{0};
+  int dev = 0;
+  MI_CHECK_HIP(hipGetDevice(&dev));
+  const unsigned bit = 1u << (dev & 31);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
     MI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bt_kernel<C, NW, MPW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, K::BYTES));
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((bt_kernel<C, NW, MPW>), dim3(grid), dim3(64 * NW), K::BYTES, st, a);
   MI_LAUNCH_CHECK();
@@ -503,7 +510,7 @@ int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dre
   a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dres = (const bf16*)dres; a.mean = mean; a.rstd = rstd; a.w = w;
   a.gamma = gamma; a.dx = (bf16*)dx; a.gpart = gpart; a.M = M; a.mpad = p.mpad; a.N = N;
   a.tiles_per_image = (int)(N / 64); a.ntiles = B * a.tiles_per_image;
-  { const char* e = getenv("MI_BT_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  { const char* e = MI_ENV(MI_BT_DEBUG); a.dbg = e ? atoi(e) : 0; }
   const int grid = a.ntiles < p.grid ? a.ntiles : p.grid;
   {
     const double px = (double)B * N;

@@ -48,6 +48,25 @@ template <> struct MfmaOp<true> {
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
 };
 
+// ---- A/B switches (environment variables) ---------------------------------------------------------------------------------
+// Every MI_* switch the launch planners consult is read ONCE, into a table, the first time the library needs one (round-2
+// verdict: 27 getenv() calls per launch on a launch-bound path, not thread-safe against setenv from another thread).  Values
+// are copied, so the pointers stay valid whatever happens to the environment.  mi_env_reload() (C-ABI) re-reads them - for
+// tests and A/B tools that flip a switch inside one process; call it with no launch planner running on another thread.
+#define MI_ENV_LIST(X)                                                                                                       \
+  X(MI_BT_WIDE) X(MI_BT_DEBUG) X(MI_DW_LDS) X(MI_FG_CFG) X(MI_FG_DEBUG) X(MI_FG_NOXCD) X(MI_GRAM_FOLD) X(MI_GRAM_WANT)      \
+  X(MI_GRAM_RECT) X(MI_GRAM_LDS) X(MI_GRAM_STREAM_ALL) X(MI_LN_FORM) X(MI_LN_BWD384) X(MI_CO_STREAM) X(MI_ATTN_DQK_SPLIT)    \
+  X(MI_PW_DMA) X(MI_PW_TM_EVEN) X(MI_PW_WAVE) X(MI_PW_CHUNKED) X(MI_PW_XWIDE) X(MI_PW_WAVE_WIDE) X(MI_PW_DIRECT)             \
+  X(MI_PW_WAVE_TPW) X(MI_PW_XCD) X(MI_PW_TPB) X(MI_FM_DEBUG) X(MI_FM_CFG) X(MI_NO_FUSED_MDTA)
+enum EnvId {
+#define MI_ENV_ENUM(n) E_##n,
+  MI_ENV_LIST(MI_ENV_ENUM)
+#undef MI_ENV_ENUM
+  E_ENV_COUNT
+};
+const char* env_get(int id);   // the variable's value as the process had it at load / last mi_env_reload(), or nullptr
+#define MI_ENV(n) ::mi::env_get(::mi::E_##n)
+
 // ---- error plumbing -------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define MI_CHECK_ARG(cond, ...)                \

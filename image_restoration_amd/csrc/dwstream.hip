@@ -609,7 +609,7 @@ static Plan make_plan(int H, int W, int64_t planes) {
 
 bool dws_eligible(int H, int W, int ks) {
   if (ks != 3 || H < 1) return false;
-  if (getenv("MI_DW_LDS")) return false;  // A/B switch: force the LDS-tiled kernels
+  if (MI_ENV(MI_DW_LDS)) return false;  // A/B switch: force the LDS-tiled kernels
   return W == 16 || W == 32 || W == 64 || W == 128 || W == 256;
 }
 

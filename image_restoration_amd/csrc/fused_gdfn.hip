@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
 // A/B switch (read per call): MI_FG_CFG=w64 selects the 8-wave 64-wide tiles; th8 / pc16 / pc32 override rows / pairs per chunk.
 struct FgSel { int th, tw, pc, nw; };
 static FgSel fg_select(int C, int H) {
-  const char* e = getenv("MI_FG_CFG");
+  const char* e = MI_ENV(MI_FG_CFG);
   FgSel f;
   if (e && strstr(e, "w64")) {
     f.tw = 64; f.nw = 8;
@@ -611,10 +611,10 @@ static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const 
   a.B = s->B; a.H = s->H; a.W = s->W; a.nch = l.nch; a.with_bias = s->ln_with_bias;
   a.tiles_x = s->W / TW; a.tiles_y = s->H / TH;
   a.f8_x1 = f8 ? f8->x1 : 1.f; a.f8_w1 = f8 ? f8->w1 : 1.f; a.f8_x2 = f8 ? f8->x2 : 1.f; a.f8_w2 = f8 ? f8->w2 : 1.f;
-  { const char* e = getenv("MI_FG_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+  { const char* e = MI_ENV(MI_FG_DEBUG); a.dbg = e ? atoi(e) : 0; }
   const int64_t tiles = (int64_t)s->B * a.tiles_x * a.tiles_y;
   MI_CHECK_ARG(tiles < (1ll << 31), "gdfn_fused: grid too large");
-  a.xcd_pairs = (TW == 32 && tiles % 16 == 0 && !getenv("MI_FG_NOXCD")) ? 1 : 0;
+  a.xcd_pairs = (TW == 32 && tiles % 16 == 0 && !MI_ENV(MI_FG_NOXCD)) ? 1 : 0;
   MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW, F8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES));
   const double N = (double)s->H * s->W * s->B, h = s->hidden;

@@ -143,6 +143,46 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ z,
   }
 }
 
+// General forms (any H, W: rows that are not a power of two in 16..256 - a 512-pixel tile, an untiled 1024^2 image, the 8 x 8
+// latent plane of a 64^2 input): one thread per output element, grid-stride.  Off the training path; they exist so that no plane
+// the three networks can produce leaves the native kernels (round-2 verdict: silent MIOpen fallbacks).
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void im2col3x3_any_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t planes, int H, int W) {
+  const int64_t HW = (int64_t)H * W, total = planes * 9 * HW;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xx = (int)(t % W);
+    const int yy = (int)((t / W) % H);
+    const int64_t pt = t / HW;
+    const int tap = (int)(pt % 9);
+    const int64_t plane = pt / 9;
+    const int src = FLIP ? 8 - tap : tap;
+    const int sy = yy + src / 3 - 1, sx = xx + src % 3 - 1;
+    T v = Cvt<T>::from(0.f);
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[plane * HW + (int64_t)sy * W + sx];
+    out[t] = v;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_any_kernel(const T* __restrict__ z, const float* __restrict__ bias,
+                                                            const T* __restrict__ residual, T* __restrict__ yout, int64_t planes,
+                                                            int M, int H, int W, int flip) {
+  const int64_t HW = (int64_t)H * W, total = planes * HW;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xx = (int)(t % W);
+    const int yy = (int)((t / W) % H);
+    const int64_t plane = t / HW;
+    float acc = bias ? bias[plane % M] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+        acc += to_f32(z[(plane * 9 + (flip ? 8 - tap : tap)) * HW + (int64_t)sy * W + sx]);
+    }
+    if (residual) acc += to_f32(residual[t]);
+    yout[t] = Cvt<T>::from(acc);
+  }
+}
+
 // PixelShuffle(2) / PixelUnshuffle(2) (Restormer.py:175-176,186-187) as one streaming pass with batch strides on both sides,
 // so that the shuffled map can land directly in (or be read back from) one half of the decoder's concatenation buffer.
 //   shuffle  : out[b][c][2y+i][2x+j] = in[b][4c+2i+j][y][x]      (in: [B,4c,H,W], out: [B,c,2H,2W])
@@ -205,7 +245,8 @@ static GPlan g_plan(int H, int W, int64_t planes) {
   p.blocks = (unsigned)((planes * p.nb + 4 * G - 1) / (4 * G));
   return p;
 }
-static bool g_ok(int H, int W) { return H >= 1 && (W == 16 || W == 32 || W == 64 || W == 128 || W == 256); }
+static bool g_fast(int H, int W) { return H >= 1 && (W == 16 || W == 32 || W == 64 || W == 128 || W == 256); }   // wave-streaming forms
+static bool g_ok(int H, int W) { return H >= 1 && W >= 1; }
 
 #define G_LPR_SWITCH(W_, ...)                                      \
   switch ((W_) / 4) {                                              \
@@ -224,13 +265,25 @@ using namespace mi;
 extern "C" int mi_glue3x3_ok(int H, int W) { return g_ok(H, W) ? 1 : 0; }
 
 extern "C" int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip, int dtype, void* stream) {
-  MI_CHECK_ARG(x && out && B > 0 && C > 0, "im2col3x3: bad arguments");
+  MI_CHECK_ARG(x && out && B > 0 && C > 0 && g_ok(H, W), "im2col3x3: bad arguments");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "im2col3x3: bad dtype %d", dtype);
-  MI_CHECK_ARG(g_ok(H, W) && aligned16(x) && aligned16(out), "im2col3x3: rows must be 16..256 pixels (power of two), planes 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t planes = (int64_t)B * C;
-  const GPlan p = g_plan(H, W, planes);
   ProfScope ps(st, K_IM2COL, 10.0 * planes * H * W * dtype_size(dtype), 0.0);
+  if (!(g_fast(H, W) && aligned16(x) && aligned16(out))) {             // general form
+    const int64_t total = planes * 9 * H * W;
+    const unsigned blocks = (unsigned)(total / 256 + 1 > 65536 ? 65536 : total / 256 + 1);
+    if (dtype == MI_F32) {
+      if (flip) hipLaunchKernelGGL((im2col3x3_any_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, planes, H, W);
+      else hipLaunchKernelGGL((im2col3x3_any_kernel<float, false>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)out, planes, H, W);
+    } else {
+      if (flip) hipLaunchKernelGGL((im2col3x3_any_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out, planes, H, W);
+      else hipLaunchKernelGGL((im2col3x3_any_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out, planes, H, W);
+    }
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
+  const GPlan p = g_plan(H, W, planes);
   if (dtype == MI_F32) {
     if (flip) { G_LPR_SWITCH(W, hipLaunchKernelGGL((im2col3x3_kernel<float, LPR, true>), dim3(p.blocks), dim3(256), 0, st, (const float*)x,
                                                    (float*)out, (int)planes, H, W, p.nb, p.band)); }
@@ -248,14 +301,24 @@ extern "C" int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W
 
 extern "C" int mi_col2im3x3(const void* z, const float* bias, const void* residual, void* y, int B, int M, int H, int W,
                             int flip, int dtype, void* stream) {
-  MI_CHECK_ARG(z && y && B > 0 && M > 0, "col2im3x3: bad arguments");
+  MI_CHECK_ARG(z && y && B > 0 && M > 0 && g_ok(H, W), "col2im3x3: bad arguments");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "col2im3x3: bad dtype %d", dtype);
-  MI_CHECK_ARG(g_ok(H, W) && aligned16(z) && aligned16(y) && aligned16(residual),
-               "col2im3x3: rows must be 16..256 pixels (power of two), planes 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t planes = (int64_t)B * M;
-  const GPlan p = g_plan(H, W, planes);
   ProfScope ps(st, K_COL2IM, (10.0 + (residual ? 1.0 : 0.0)) * planes * H * W * dtype_size(dtype), 9.0 * planes * H * W);
+  if (!(g_fast(H, W) && aligned16(z) && aligned16(y) && aligned16(residual))) {   // general form
+    const int64_t total = planes * H * W;
+    const unsigned blocks = (unsigned)(total / 256 + 1 > 65536 ? 65536 : total / 256 + 1);
+    if (dtype == MI_F32)
+      hipLaunchKernelGGL((col2im3x3_any_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)z, bias, (const float*)residual,
+                         (float*)y, planes, M, H, W, flip);
+    else
+      hipLaunchKernelGGL((col2im3x3_any_kernel<bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)z, bias, (const bf16*)residual,
+                         (bf16*)y, planes, M, H, W, flip);
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
+  const GPlan p = g_plan(H, W, planes);
   if (dtype == MI_F32) {
     G_LPR_SWITCH(W, hipLaunchKernelGGL((col2im3x3_kernel<float, LPR>), dim3(p.blocks), dim3(256), 0, st, (const float*)z, bias,
                                        (const float*)residual, (float*)y, (int)planes, M, H, W, p.nb, p.band, flip));
@@ -271,23 +334,24 @@ extern "C" int mi_pixel_shuffle2(const void* in, int64_t in_bs, void* out, int64
                                  int unshuffle, int dtype, void* stream) {
   MI_CHECK_ARG(in && out && B > 0 && c > 0 && H > 0 && W > 0, "pixel_shuffle2: bad arguments");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "pixel_shuffle2: bad dtype %d", dtype);
-  const int V = dtype == MI_BF16 ? 8 : 4;           // 16-byte accesses on the planar side
-  MI_CHECK_ARG(W % V == 0 && aligned16(in) && aligned16(out), "pixel_shuffle2: W must be a multiple of %d, pointers 16-byte aligned", V);
   const int64_t dense_lo = (int64_t)4 * c * H * W;  // both sides hold 4*c*H*W elements per image
   const int64_t ibs = in_bs ? in_bs : dense_lo, obs = out_bs ? out_bs : dense_lo;
-  MI_CHECK_ARG(ibs % V == 0 && obs % V == 0, "pixel_shuffle2: batch strides must keep 16-byte alignment");
+  int V = dtype == MI_BF16 ? 8 : 4;                 // 16-byte accesses on the planar side ...
+  if (W % V != 0 || !aligned16(in) || !aligned16(out) || ibs % V != 0 || obs % V != 0) V = 1;   // ... or the element-wise general form
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)B * c * 2 * H * (W / V);
   int blocks = cdiv(total, 256);
   if (blocks > 16384) blocks = 16384;
   ProfScope ps(st, K_COL2IM, 2.0 * B * dense_lo * dtype_size(dtype), 0.0);
+#define PS_LAUNCH(T, VV, UN) hipLaunchKernelGGL((pixel_shuffle_kernel<T, VV, UN>), dim3(blocks), dim3(256), 0, st, (const T*)in, (T*)out, c, H, W, ibs, obs, total)
   if (dtype == MI_BF16) {
-    if (unshuffle) hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, 8, true>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, c, H, W, ibs, obs, total);
-    else hipLaunchKernelGGL((pixel_shuffle_kernel<bf16, 8, false>), dim3(blocks), dim3(256), 0, st, (const bf16*)in, (bf16*)out, c, H, W, ibs, obs, total);
+    if (V == 8) { if (unshuffle) PS_LAUNCH(bf16, 8, true); else PS_LAUNCH(bf16, 8, false); }
+    else { if (unshuffle) PS_LAUNCH(bf16, 1, true); else PS_LAUNCH(bf16, 1, false); }
   } else {
-    if (unshuffle) hipLaunchKernelGGL((pixel_shuffle_kernel<float, 4, true>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, c, H, W, ibs, obs, total);
-    else hipLaunchKernelGGL((pixel_shuffle_kernel<float, 4, false>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, c, H, W, ibs, obs, total);
+    if (V == 4) { if (unshuffle) PS_LAUNCH(float, 4, true); else PS_LAUNCH(float, 4, false); }
+    else { if (unshuffle) PS_LAUNCH(float, 1, true); else PS_LAUNCH(float, 1, false); }
   }
+#undef PS_LAUNCH
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -296,18 +360,22 @@ extern "C" int mi_copy_rows(const void* src, int64_t src_rs, void* dst, int64_t 
                             void* stream) {
   MI_CHECK_ARG(src && dst && rows > 0 && L > 0, "copy_rows: bad arguments");
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "copy_rows: bad dtype %d", dtype);
-  const int V = dtype == MI_BF16 ? 8 : 4;
+  int V = dtype == MI_BF16 ? 8 : 4;
   if (!src_rs) src_rs = L;
   if (!dst_rs) dst_rs = L;
-  MI_CHECK_ARG(L % V == 0 && src_rs % V == 0 && dst_rs % V == 0 && aligned16(src) && aligned16(dst),
-               "copy_rows: rows must be 16-byte aligned and a multiple of 16 bytes long");
+  if (L % V != 0 || src_rs % V != 0 || dst_rs % V != 0 || !aligned16(src) || !aligned16(dst)) V = 1;   // element-wise general form
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = rows * (L / V);
   int blocks = cdiv(total, 256);
   if (blocks > 16384) blocks = 16384;
   ProfScope ps(st, K_CAST, 2.0 * rows * L * dtype_size(dtype), 0.0);
-  if (dtype == MI_BF16) hipLaunchKernelGGL((copy_rows_kernel<bf16, 8>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, src_rs, (bf16*)dst, dst_rs, L, total);
-  else hipLaunchKernelGGL((copy_rows_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)src, src_rs, (float*)dst, dst_rs, L, total);
+  if (dtype == MI_BF16) {
+    if (V == 8) hipLaunchKernelGGL((copy_rows_kernel<bf16, 8>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, src_rs, (bf16*)dst, dst_rs, L, total);
+    else hipLaunchKernelGGL((copy_rows_kernel<bf16, 1>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, src_rs, (bf16*)dst, dst_rs, L, total);
+  } else {
+    if (V == 4) hipLaunchKernelGGL((copy_rows_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)src, src_rs, (float*)dst, dst_rs, L, total);
+    else hipLaunchKernelGGL((copy_rows_kernel<float, 1>), dim3(blocks), dim3(256), 0, st, (const float*)src, src_rs, (float*)dst, dst_rs, L, total);
+  }
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

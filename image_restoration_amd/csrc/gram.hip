@@ -431,7 +431,7 @@ struct GramPlan { int FA, FB, kc, nchunks, tiles_a, tiles_b, splits, cps, Z, fol
 // 102 -> 76 us, 2042 x 384 144 -> 127 us) and where images x tiles leaves the chip half empty (576 x 192 at 64 x 64: 320
 // workgroups, 163 -> 125 us); on long planes the per-chunk image lookup costs 5-10 % and buys nothing, so those stay per image.
 static int gram_fold(const mi_gram_desc* d, int unit, int64_t tiles_per_image) {
-  const char* e = getenv("MI_GRAM_FOLD");                            // A/B switch: 0 never, 2 wherever possible
+  const char* e = MI_ENV(MI_GRAM_FOLD);                            // A/B switch: 0 never, 2 wherever possible
   if (e && e[0] == '0') return 0;
   if (!d->sum_batch || d->batch <= 1 || d->sumsq || d->n % unit != 0 || d->n / unit > (1 << 20)) return 0;
   // (second case: the per-image plan would run ONE split - 512 / workgroups rounds to 1 - on a chip it does not fill)
@@ -441,7 +441,7 @@ static int gram_fold(const mi_gram_desc* d, int unit, int64_t tiles_per_image) {
   return (int)(d->n / unit);
 }
 static int gram_want(int dflt) {
-  const char* e = getenv("MI_GRAM_WANT");                            // A/B switch: workgroups the pixel split aims for
+  const char* e = MI_ENV(MI_GRAM_WANT);                            // A/B switch: workgroups the pixel split aims for
   return e ? atoi(e) : dflt;
 }
 
@@ -454,7 +454,7 @@ static GramPlan gram_plan(const mi_gram_desc* d) {
   // 158 -> 116, 576 x 192 124 -> 85, 2042 x 384 128 -> 105 (384 x 384 loses: 35 -> 39, stays square); step 153.6 -> 152.1 ms.
   // MI_GRAM_RECT=0: square tiles only (A/B switch).
   {
-    const char* e = getenv("MI_GRAM_RECT");
+    const char* e = MI_ENV(MI_GRAM_RECT);
     if (d->dtype == MI_BF16 && !(e && e[0] == '0') && d->ma > 64 && d->ma <= 96 && d->mb > 64 && d->mb <= 96) {
       g.FA = g.FB = 3;                                               // 96 x 96 (q k^T and dM at c = 96): no padded fragments
     } else if (d->dtype == MI_BF16 && !d->sumsq && !(e && e[0] == '0')) {
@@ -520,7 +520,7 @@ static bool gram_direct(const mi_gram_desc* d, int splits) {
   return splits == 1 && !d->sum_batch && !d->accumulate && d->out_ld == d->mb && d->out_zs == (int64_t)d->ma * d->mb;
 }
 static bool gram_stream_ok(const mi_gram_desc* d) {
-  if (d->dtype != MI_BF16 || getenv("MI_GRAM_LDS")) return false;
+  if (d->dtype != MI_BF16 || MI_ENV(MI_GRAM_LDS)) return false;
   bool ok = (d->n % 8 == 0) && aligned16(d->a) && aligned16(d->b);
   ok = ok && d->a_bs % 8 == 0 && d->a_gs % 8 == 0 && d->b_bs % 8 == 0 && d->b_gs % 8 == 0;
   if (!ok) return false;
@@ -528,7 +528,7 @@ static bool gram_stream_ok(const mi_gram_desc* d) {
   // output (48x48 q k^T, the 144/254/127 x 48 weight gradients: 1.1-1.7x); with 96-wide or many tiles the operand
   // re-reads and 1-wave occupancy lose to the LDS-staged 128x128 tiles (0.6-0.85x).
   const GramSPlan g = gram_splan(d);
-  if (getenv("MI_GRAM_STREAM_ALL")) return true;   // A/B switch
+  if (MI_ENV(MI_GRAM_STREAM_ALL)) return true;   // A/B switch
   if ((g.fold ? (int64_t)d->batch * d->n : d->n) < 4096) return false;
   if (g.fa <= 4 && g.fb <= 4 && g.tiles_a * g.tiles_b <= 4) return true;
   // ... and where the 128 x 128 LDS tiles would be mostly padding (288 x 96 fills 56% of 3 x 1 tiles: streaming 1.27x

@@ -460,8 +460,8 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_wave_kernel(const T* __restric
 // 1.2-1.75x up to C = 192 (4.7-5.1 TB/s against 2.7-2.9); backward with 24-channel slices wins 1.05-2.3x up to C = 192.
 static bool ln_wave_form(int C, bool bwd) {
   if (C > 384) return false;
-  if (const char* e = getenv("MI_LN_FORM")) return e[0] == 'w';
-  return bwd ? C <= (getenv("MI_LN_BWD384") ? 384 : 192) : C <= 192;
+  if (const char* e = MI_ENV(MI_LN_FORM)) return e[0] == 'w';
+  return bwd ? C <= (MI_ENV(MI_LN_BWD384) ? 384 : 192) : C <= 192;
 }
 struct LnCfg { int waves, cpt, vec; };
 static LnCfg ln_cfg(int C, bool bwd, bool f32) {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gelu_gap_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ gating products
-// op 0: out = a * b ; op 1: out = a * silu(b)
+// op 0: out = a * b ; op 1: out = a * silu(b) ; op 2: out = gelu_erf(a) (b unused; FrequencyEmbedding's MLP activation, :1071)
 template <typename T>
 __global__ __launch_bounds__(256) void ewise_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
                                                         int64_t n, int op, int64_t L, int64_t a_rs, int64_t b_rs) {
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void ewise_fwd_kernel(const T* __restrict__ a,
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const int64_t r = i / L, c = i - r * L;
     const float av = to_f32(a[r * a_rs + c]), bv = to_f32(b[r * b_rs + c]);
+    if (op == 2) { out[i] = Cvt<T>::from(gelu_erf(av)); continue; }
     const float f = op == 0 ? bv : bv / (1.f + __expf(-bv));
     out[i] = Cvt<T>::from(av * f);
   }
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void ewise_bwd_kernel(const T* __restrict__ a,
     const int64_t r = i / L, c = i - r * L;
     const float av = to_f32(a[r * a_rs + c]), bv = to_f32(b[r * b_rs + c]), g = to_f32(dout[i]);
     float f, df;
+    if (op == 2) { da[r * da_rs + c] = Cvt<T>::from(g * gelu_erf_grad(av)); continue; }
     if (op == 0) { f = bv; df = 1.f; }
     else { const float s = 1.f / (1.f + __expf(-bv)); f = bv * s; df = s * (1.f + bv * (1.f - s)); }
     da[r * da_rs + c] = Cvt<T>::from(g * f);
@@ -436,7 +438,7 @@ extern "C" int mi_gelu_gap_bwd(const void* x, const float* dout, void* dx, int B
 extern "C" int mi_ewise_fwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, void* out, int64_t rows, int64_t L, int op,
                             int dtype, void* stream) {
   const int64_t n = rows * L;
-  MI_CHECK_ARG(a && b && out && rows > 0 && L > 0 && (op == 0 || op == 1), "ewise_fwd: bad arguments");
+  MI_CHECK_ARG(a && b && out && rows > 0 && L > 0 && op >= 0 && op <= 2, "ewise_fwd: bad arguments");
   if (!a_rs) a_rs = L;
   if (!b_rs) b_rs = L;
   hipStream_t st = (hipStream_t)stream;
@@ -452,7 +454,7 @@ extern "C" int mi_ewise_fwd(const void* a, int64_t a_rs, const void* b, int64_t 
 extern "C" int mi_ewise_bwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, const void* dout, void* da, int64_t da_rs,
                             void* db, int64_t db_rs, int64_t rows, int64_t L, int op, int dtype, void* stream) {
   const int64_t n = rows * L;
-  MI_CHECK_ARG(a && b && dout && da && db && rows > 0 && L > 0 && (op == 0 || op == 1), "ewise_bwd: bad arguments");
+  MI_CHECK_ARG(a && b && dout && da && db && rows > 0 && L > 0 && op >= 0 && op <= 2, "ewise_bwd: bad arguments");
   if (!a_rs) a_rs = L;
   if (!b_rs) b_rs = L;
   if (!da_rs) da_rs = L;

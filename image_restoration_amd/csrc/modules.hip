@@ -38,8 +38,8 @@ struct CoStream {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 static bool co_stream_enabled() {
-  static const int on = [] { const char* e = getenv("MI_CO_STREAM"); return e && atoi(e) == 1 ? 1 : 0; }();
-  return on != 0;
+  const char* e = MI_ENV(MI_CO_STREAM);
+  return e && atoi(e) == 1;
 }
 static CoStream* co_stream() {
   static thread_local CoStream cs[16];
@@ -201,7 +201,7 @@ static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, 
   // both in one pass over q and k where the GEMM form can write two outputs (bf16 wave-owned forms), else one GEMM each
   const int c = C / hd;
   mi_pw_desc dd = attn_dqk_merged(d, v, w.wd, dq, dq_bs, dk, dk_bs);
-  if (mi_pw_gemm_split_ok(&dd) && !getenv("MI_ATTN_DQK_SPLIT")) {
+  if (mi_pw_gemm_split_ok(&dd) && !MI_ENV(MI_ATTN_DQK_SPLIT)) {
     MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
   } else {
     dd = attn_dqk_desc(d, v, w.wd, 0, c, dq, dq_bs);

@@ -1182,7 +1182,7 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
   // m_tiles * (K + tm); 96- and 48-row tiles keep 96- / 48- / 144- / 288-channel matrices from being padded by a third
   // (ties go to the larger tile; the LDS-DMA kernel only has 64 / 128).
   {
-    const bool dma = getenv("MI_PW_DMA") != nullptr || getenv("MI_PW_TM_EVEN") != nullptr;   // (the latter: A/B switch)
+    const bool dma = MI_ENV(MI_PW_DMA) != nullptr || MI_ENV(MI_PW_TM_EVEN) != nullptr;   // (the latter: A/B switch)
     const int ktot = d->k1 + d->k2;
     int64_t best_cost = 0;
     pl.tm = 0;
@@ -1200,11 +1200,11 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
   // wave-owned forms (1: xres, 2: stream) where their LDS budget holds; they fix the packed tile height
   pl.wave = 0;
   {
-    const char* e = getenv("MI_PW_WAVE");
-    const bool off = (e && e[0] == '0') || getenv("MI_PW_DMA") || getenv("MI_PW_CHUNKED");
+    const char* e = MI_ENV(MI_PW_WAVE);
+    const bool off = (e && e[0] == '0') || MI_ENV(MI_PW_DMA) || MI_ENV(MI_PW_CHUNKED);
     if (allow_wave && !off && d->dtype == MI_BF16 && d->n % PW_TN == 0 && pw_vec_ok(d)) {
       const size_t patches = (size_t)PWW_MW * PWW_PATCH * sizeof(bf16), row = PwRow<bf16>::WS_ROW * sizeof(bf16);
-      const char* xw = getenv("MI_PW_XWIDE");                          // A/B switch
+      const char* xw = MI_ENV(MI_PW_XWIDE);                          // A/B switch
       if (d->m > 96 && pl.k_chunks <= 3 && (size_t)pl.k_chunks * cdiv(d->m, 64) * 64 * row + patches + 768 <= PWW_LDS_MAX) {
         pl.wave = 1; pl.tm = 64;
       } else if (d->m >= 256 && pl.k_chunks >= 4 && pl.k_chunks <= 6 && !(xw && xw[0] == '0')) {   // (192 x 192 measured better on the streaming form)
@@ -1221,7 +1221,7 @@ static PwPlan pw_plan(const mi_pw_desc* d, bool allow_wave = true) {
           const int64_t cost = (int64_t)cdiv(d->m, tm) * (d->k1 + d->k2 + tm);
           if (!best || cost < best_cost) { best = tm; best_cost = cost; }
         }
-        const char* w = getenv("MI_PW_WAVE_WIDE");
+        const char* w = MI_ENV(MI_PW_WAVE_WIDE);
         if (best && (d->m <= 96 || !(w && w[0] == '0'))) { pl.wave = 2; pl.tm = best; }
       }
     }
@@ -1303,7 +1303,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   // MI_PW_DIRECT=1 (A/B switch, off): per-image weights on a wave-owned form without a packed image - the kernels stage them from
   // fp32.  Measured SLOWER (profiles/r02_m_per_image_weights_direct_ab.txt: 165.0 vs 157.2 ms per step): every one of the ~2000
   // workgroups of such a GEMM repeats the scalar fp32 -> bf16 walk that one 7 us pack launch does once.
-  const bool direct = pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && getenv("MI_PW_DIRECT");
+  const bool direct = pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && MI_ENV(MI_PW_DIRECT);
   const unsigned char* cached = direct ? nullptr : pw_cache_lookup(job, pl.bytes, st);
   if (!cached && !direct) {  // re-pack the weights of every slice (and refresh the zero block)
     const int64_t total = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * PW_KC;
@@ -1345,7 +1345,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   // The LDS-DMA ring measured 5-12% SLOWER than register staging on every Restormer shape (K is 2-16 chunks, so the
   // per-tile prologue and epilogue dominate and its 3 x chunk LDS footprint halves the resident workgroups).  It stays
   // opt-in (MI_PW_DMA=1) as the base of a persistent cross-tile pipeline; tests run it through the same parity cases.
-  const bool dma = getenv("MI_PW_DMA") != nullptr;
+  const bool dma = MI_ENV(MI_PW_DMA) != nullptr;
   if (pl.wave) {
     if constexpr (std::is_same<T, bf16>::value) {
       const int64_t n_tiles = k.n / PW_TN;
@@ -1356,7 +1356,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
       int64_t tpw = wbytes > 96 * 1024 ? 4 : 2;
       const int64_t par = n_tiles * grid.z * (pl.wave == 2 ? pl.m_tiles : 1) / ((int64_t)PWW_MW * 256 * 4);
       if (tpw > par) tpw = par;
-      if (const char* e = getenv("MI_PW_WAVE_TPW")) tpw = atoi(e);
+      if (const char* e = MI_ENV(MI_PW_WAVE_TPW)) tpw = atoi(e);
       if (tpw < 1) tpw = 1;
       if (tpw > 8) tpw = 8;
       dim3 wgrid((unsigned)cdiv(n_tiles, tpw * PWW_MW), pl.wave == 2 ? pl.m_tiles : 1, grid.z), wblock(64 * PWW_MW);
@@ -1373,7 +1373,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
         lds = (size_t)2 * pl.k_chunks * sr * row + patches + (d->ln_mode ? (size_t)2 * pl.k_chunks * PW_KC * sizeof(float) : 0);
       }
       {
-        const char* e = getenv("MI_PW_XCD");                           // A/B switch
+        const char* e = MI_ENV(MI_PW_XCD);                           // A/B switch
         const int min_tiles = e ? atoi(e) : 0;   // off by default: measured no gain (profiles/r02_i_pw_xcd_map_ab.txt)
         const uint64_t total = (uint64_t)wgrid.x * wgrid.y * wgrid.z;
         q.xcd_map = (pl.wave == 2 && min_tiles > 0 && (int)wgrid.y >= min_tiles && total % 8 == 0 && total < (1ull << 31)) ? 1 : 0;
@@ -1415,7 +1415,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   } else if (k.vec_ok && dma) {
     if (pl.tm == 128) MI_TRY((pw_launch_dma<T, 2>(q, grid, st)));
     else MI_TRY((pw_launch_dma<T, 1>(q, grid, st)));
-  } else if (std::is_same<T, bf16>::value && k.vec_ok && pl.k_chunks <= PWR_MAXC && k.m > 64 && !getenv("MI_PW_CHUNKED")) {
+  } else if (std::is_same<T, bf16>::value && k.vec_ok && pl.k_chunks <= PWR_MAXC && k.m > 64 && !MI_ENV(MI_PW_CHUNKED)) {
     // (M <= 64 stays chunked: 48 x 48 is a tie and 48 x 127 loses 13%; profiles/r01_y_pw_resident_bs32.log)
     // weight-resident persistent kernel (K <= 128).  Things that did NOT help the chunked kernel beyond the Infinity Cache
     // (bs 32; profiles/r01_v_pw_*bs32*.log): a 128 x 128 tile, also persistent and cross-tile pipelined (-10..25%: 2-3
@@ -1427,7 +1427,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
     const size_t lds = ((size_t)pl.k_chunks * wc + xbuf) * sizeof(bf16);
     // pixel tiles per workgroup: enough to amortise the weight load, while >= 2048 workgroups remain
     int64_t tpb = (int64_t)n_tiles * pl.m_tiles * grid.z / 2048;
-    if (const char* e = getenv("MI_PW_TPB")) tpb = atoi(e);
+    if (const char* e = MI_ENV(MI_PW_TPB)) tpb = atoi(e);
     if (tpb < 1) tpb = 1;
     if (tpb > 32) tpb = 32;
     dim3 rgrid((unsigned)cdiv(n_tiles, tpb), pl.m_tiles, grid.z);

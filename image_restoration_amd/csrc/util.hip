@@ -1,5 +1,6 @@
 // Small shared kernels: deterministic row reduction, AdamW on flat buffers, casts, L1 loss.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -15,6 +16,28 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---------------------------------------------------------------- A/B switches, read once (common.h: MI_ENV)
+struct EnvTable { char val[E_ENV_COUNT][48]; bool set[E_ENV_COUNT]; };
+static EnvTable g_env;
+static std::once_flag g_env_once;
+static void env_load() {
+  static const char* const names[E_ENV_COUNT] = {
+#define MI_ENV_NAME(n) #n,
+      MI_ENV_LIST(MI_ENV_NAME)
+#undef MI_ENV_NAME
+  };
+  for (int i = 0; i < E_ENV_COUNT; ++i) {
+    const char* e = getenv(names[i]);
+    g_env.set[i] = e != nullptr;
+    g_env.val[i][0] = 0;
+    if (e) { strncpy(g_env.val[i], e, sizeof(g_env.val[i]) - 1); g_env.val[i][sizeof(g_env.val[i]) - 1] = 0; }
+  }
+}
+const char* env_get(int id) {
+  std::call_once(g_env_once, env_load);
+  return (id >= 0 && id < E_ENV_COUNT && g_env.set[id]) ? g_env.val[id] : nullptr;
 }
 
 // ---------------------------------------------------------------- profiler
@@ -215,6 +238,11 @@ extern "C" int mi_prof_collect(double* ms, double* bytes, double* flops, int64_t
   return MI_OK;
 }
 extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" int mi_env_reload(void) {
+  std::call_once(mi::g_env_once, mi::env_load);
+  mi::env_load();
+  return MI_OK;
+}
 
 extern "C" int mi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float grad_scale, const float* dev_scalars,

@@ -63,7 +63,8 @@ def draw_batch_plan(pool: ImagePool, batch: int, patch: int, sigmas: Sequence[fl
     left = (torch.rand(batch, generator=gen) * (hw[:, 1] - patch + 1).float()).long().clamp_(min=0)
     top = torch.minimum(top, hw[:, 0] - patch)
     left = torch.minimum(left, hw[:, 1] - patch)
-    mode = torch.randint(0, 8, (batch,), generator=gen)
+    # random_augmentation draws random.randint(1, 7) (image_utils.py:182, both ends inclusive): the identity (mode 0) is never taken
+    mode = torch.randint(1, 8, (batch,), generator=gen)
     sig = torch.tensor(list(sigmas), dtype=torch.float32)[torch.randint(0, len(sigmas), (batch,), generator=gen)]
     return sample.int(), top.int(), left.int(), mode.int(), sig
 

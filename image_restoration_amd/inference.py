@@ -43,18 +43,36 @@ class PackedWeights:
         dev = params[0].device
         if dev.type != "cuda" or any(p.dtype != torch.float32 or p.device != dev for p in params):
             raise RuntimeError("PackedWeights: fp32 parameters on one MI355X")
+        self._ops = ops
+        self._params = params
+        self._hooks = []
+        self._token = None
+        self._saved_data = None
+        # A model a FlatTrainer owns (its parameters are views of the trainer's flat buffer and carry main_grad) already has a
+        # cache owner that follows every weight update: per-epoch validation inside a training run borrows it.  Moving the
+        # parameters into a second flat buffer here would cut them loose from the buffer AdamW updates - training would go on
+        # "updating" memory the model no longer reads.
+        self._borrowed = any(getattr(p, "main_grad", None) is not None for p in params)
+        if self._borrowed:
+            if ops.pw_cache_owner() is None:
+                raise RuntimeError("PackedWeights: the model's parameters belong to a FlatTrainer whose packed-weight cache is "
+                                   "closed; validate without PackedWeights or keep the trainer's cache (pack_cache=True)")
+            self.flat = None
+            self._open = True
+            return
         offs, total = [], 0
         for p in params:
             offs.append(total)
             total += (p.numel() + 63) // 64 * 64
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._saved_data = [p.data for p in params]
         with torch.no_grad():
             for p, o in zip(params, offs):
                 self.flat[o:o + p.numel()].copy_(p.reshape(-1))
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
-        self._ops = ops
-        self._params = params
-        ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat)
+        # (the cache is process-global: a previous owner - some other model's trainer - falls back to per-call weight packing,
+        #  which is always correct; its own close() no longer matches the owner token and leaves this cache alone)
+        self._token = ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat)
         self._version = self._weights_version()
         self._hooks = [model.register_load_state_dict_post_hook(lambda *_: self.refresh()),
                        model.register_forward_pre_hook(lambda *_: self._check())]
@@ -65,20 +83,31 @@ class PackedWeights:
         return self.flat._version + sum(p._version for p in self._params)
 
     def refresh(self) -> None:
-        if self._open:
+        if self._open and not self._borrowed:
+            self._ops.bump_weights_epoch()
             self._ops.pw_cache_refresh()
             self._version = self._weights_version()
 
     def _check(self) -> None:
-        if self._open and (self._weights_version() != self._version or self._ops.pw_cache_pending()):
+        if self._open and not self._borrowed and (self._weights_version() != self._version or self._ops.pw_cache_pending()):
             self.refresh()
 
     def close(self) -> None:
-        if self._open:
-            self._ops.pw_cache_enable(0, self.flat.device, None)
-            for h in self._hooks:
-                h.remove()
-            self._open = False
+        if not self._open:
+            return
+        self._open = False
+        if self._borrowed:
+            return
+        self._ops.pw_cache_release(self._token)
+        self._token = None
+        for h in self._hooks:
+            h.remove()
+        # hand the parameters back their own storage (current values): nothing keeps aliasing the flat buffer
+        with torch.no_grad():
+            for p, old in zip(self._params, self._saved_data):
+                old.copy_(p.data)
+                p.data = old
+        self._saved_data = None
 
     def __enter__(self):
         return self

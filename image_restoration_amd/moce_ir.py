@@ -27,11 +27,10 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .restormer import (Attention, Downsample, FeedForward, LayerNorm, OverlapPatchEmbed, Upsample, _apply,  # noqa: F401
-                        _BlockFn, _Conv1x1Fn, _CrossAttentionFn, _DwConvFn, _conv2d, _grad_mode, _main_grads)
+                        _BlockFn, block_apply, _Conv1x1Fn, _conv1x1_module, _CrossAttentionFn, _DwConvFn, _conv2d, _grad_mode, _main_grads)
 
 __all__ = ["SparseDispatcher", "LayerNorm", "FeedForward", "Attention", "CrossAttention", "FFTAttention", "MySequential",
            "ModExpert", "AdapterLayer", "RoutingFunction", "EncoderBlock", "DecoderBlock", "HighPassConv2d",
@@ -88,6 +87,23 @@ class _GeluGapFn(torch.autograd.Function):
     def backward(ctx, dout):
         (x,) = ctx.saved_tensors
         return ops.gelu_gap_bwd(x, dout)
+
+
+class _GeluFn(torch.autograd.Function):
+    """erf-form GELU of a small tensor (FrequencyEmbedding's MLP activation, :1071) on the gating kernel (op 2)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        a4 = a.contiguous().view(1, 1, 1, -1)
+        ctx.save_for_backward(a4)
+        ctx.shape = a.shape
+        return ops.ewise_fwd(a4, a4, 2).view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (a4,) = ctx.saved_tensors
+        da, _ = ops.ewise_bwd(a4, a4, dout.contiguous().view(1, 1, 1, -1), 2, db=a4)    # db is not written for op 2
+        return da.view(ctx.shape)
 
 
 class _EwiseFn(torch.autograd.Function):
@@ -327,23 +343,11 @@ class FFTAttention(nn.Module):
         q = _dw(_c1(x, self.q), self.q_dwconv)
         kv = _dw(_c1(x, self.kv), self.kv_dwconv)
         if self.patch_size not in (4, 8, 16, 32):
-            return self._forward_fft(x, q, kv)
+            # the reference configurations use 2 ** (i + 2), i < 4 (moce_ir.py:612); other sizes have no native kernel and
+            # there is no FFT-library path
+            raise NotImplementedError(f"FFTAttention: patch_size {self.patch_size} has no native kernel (built: 4, 8, 16, 32)")
         core = _apply(_FFTCoreFn, q, kv, self.norm.body.weight, self.norm.body.bias, self.patch_size)
         return _c1(core, self.proj_out)
-
-    def _forward_fft(self, x, q, kv):
-        """Patch sizes outside the native kernel's set (the reference configurations use 4, 8, 16, 32) go through rocFFT."""
-        b, c, h, w = x.shape
-        p = self.patch_size
-        k, v = kv.chunk(2, dim=1)
-
-        def patches(t):
-            t = F.pad(t, (0, (p - w % p) % p, 0, (p - h % p) % p))
-            return t.reshape(b, c, t.shape[-2] // p, p, t.shape[-1] // p, p).permute(0, 1, 2, 4, 3, 5)
-        out = torch.fft.irfft2(torch.fft.rfft2(patches(q).float()) * torch.fft.rfft2(patches(k).float()), s=(p, p))
-        hh, ww = out.shape[2], out.shape[3]
-        out = out.permute(0, 1, 2, 4, 3, 5).reshape(b, c, hh * p, ww * p)[:, :, :h, :w].to(x.dtype).contiguous()
-        return _c1((self.norm(out) * v).contiguous(), self.proj_out)
 
 
 class MySequential(nn.Sequential):
@@ -491,7 +495,7 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x):
         params = self.norms[0]._params() + self.mixer._params() + self.norms[1]._params() + self.ffn._params()
-        return _apply(_BlockFn, x, self.mixer.num_heads, *params)
+        return block_apply(x, self.mixer.num_heads, params)
 
 
 class DecoderBlock(nn.Module):
@@ -556,7 +560,7 @@ class FrequencyEmbedding(nn.Module):
     def forward(self, x):
         pooled = _GeluGapFn.apply(self.high_conv[0](x).contiguous())          # [B, dim] fp32 ; GELU + mean in one pass
         h = _linear_rows(pooled, self.mlp[0])
-        return _linear_rows(F.gelu(h), self.mlp[2])
+        return _linear_rows(_GeluFn.apply(h), self.mlp[2])
 
 
 class EncoderResidualGroup(nn.Module):
@@ -650,7 +654,7 @@ class MoCEIR(nn.Module):
         aux = 0
         for up, fuse, group in self.dec:
             # fusion(cat([up(feats), skip])) as ONE two-panel 1x1 GEMM: the concatenated tensor never exists (:1222)
-            feats = _apply(_Conv1x1Fn, up(feats), skips.pop(), fuse.weight, fuse.bias)
+            feats = _conv1x1_module(up(feats), skips.pop(), fuse)
             feats = group(feats, freq_emb)
             aux = aux + group.loss
         feats = self.refinement(feats)

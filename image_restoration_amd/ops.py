@@ -55,6 +55,41 @@ def _blob(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ----------------------------------------------------------------------------- A/B switches (environment variables)
+# Read once per process (a TransformerBlock forward used to make eight os.environ look-ups); ``reload_env()`` re-reads them here
+# and in the library (mi_env_reload) - for tests and A/B tools that flip a switch inside one process.
+_ENV: dict = {}
+_WEIGHTS_EPOCH = [0]
+
+
+def env(name: str) -> Optional[str]:
+    """Value of an MI_* switch as the process had it at first use / the last reload_env(); None when unset or empty."""
+    try:
+        return _ENV[name]
+    except KeyError:
+        v = os.environ.get(name) or None
+        _ENV[name] = v
+        return v
+
+
+def reload_env() -> None:
+    global _WS_CACHE_ON
+    _ENV.clear()
+    _WS_CACHE_ON = os.environ.get("MI_WS_CACHE", "1") != "0"
+    if L._lib is not None:
+        L.check(L.lib().mi_env_reload(), "env_reload")
+
+
+def weights_epoch() -> int:
+    """Counter of parameter updates torch cannot see (the fused AdamW kernel writes through raw pointers and bumps no version
+    counter): every cache of data derived from the weights keys on it (restormer._fused_gdfn_pack, the fp8 scales)."""
+    return _WEIGHTS_EPOCH[0]
+
+
+def bump_weights_epoch() -> None:
+    _WEIGHTS_EPOCH[0] += 1
+
+
 _WS_CACHE: dict = {}
 _WS_CACHE_ON = os.environ.get("MI_WS_CACHE", "1") != "0"
 
@@ -432,7 +467,7 @@ def gdfn_fwd(x: Tensor, residual: Optional[Tensor], params: GdfnParamsT, need_sa
         return out
     # A/B switch: keep the conv output instead of recomputing it in backward.  Read here, once per forward; backward
     # recovers the choice from the blob's size, so toggling the variable between the two cannot desynchronise them.
-    s = _gdfn_shape(x, hidden, ks, 1 if os.environ.get("MI_GDFN_STORE_Y") else 0)
+    s = _gdfn_shape(x, hidden, ks, 1 if env("MI_GDFN_STORE_Y") else 0)
     lib = L.lib()
     out = torch.empty_like(x)
     saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(s)), x.device) if need_saved else None
@@ -801,20 +836,38 @@ def l1_loss(a: Tensor, b: Tensor, want_grad: bool = True, scale: float = 1.0):
 _pw_cache_buf: Optional[Tensor] = None
 
 
-def pw_cache_enable(nbytes: int, device, params: Optional[Tensor] = None) -> None:
+def pw_cache_enable(nbytes: int, device, params: Optional[Tensor] = None) -> Optional[Tensor]:
     """Lend the library a device buffer for packed 1x1 weights (include/mi_restore.h: mi_pw_cache_*).  `params` is the
     storage that holds the weights (e.g. the trainer's flat parameter buffer): only matrices inside it are cached.  The
-    caller promises to call pw_cache_refresh() after every in-place weight update (or pw_cache_invalidate())."""
+    caller promises to call pw_cache_refresh() after every in-place weight update (or pw_cache_invalidate()).
+    Returns the owner token (the lent buffer): hand it to pw_cache_release() - the cache is process-global, and only the
+    object whose buffer it still points at may switch it off."""
     global _pw_cache_buf
     if nbytes <= 0 or params is None:
         L.check(L.lib().mi_pw_cache_enable(None, 0, None, None), "pw_cache_enable")
         _pw_cache_buf = None
-        return
+        return None
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     lo = params.data_ptr()
     L.check(L.lib().mi_pw_cache_enable(buf.data_ptr(), nbytes, lo, lo + params.numel() * params.element_size()),
             "pw_cache_enable")
     _pw_cache_buf = buf  # keeps the memory alive for as long as the cache points at it
+    return buf
+
+
+def pw_cache_owner() -> Optional[Tensor]:
+    return _pw_cache_buf
+
+
+def pw_cache_release(token: Optional[Tensor]) -> bool:
+    """Switch the cache off if (and only if) it still belongs to `token`'s owner.  A later owner (a second trainer, a
+    PackedWeights made afterwards) keeps its cache when an earlier object is closed or garbage-collected."""
+    global _pw_cache_buf
+    if token is None or _pw_cache_buf is not token:
+        return False
+    L.check(L.lib().mi_pw_cache_enable(None, 0, None, None), "pw_cache_enable")
+    _pw_cache_buf = None
+    return True
 
 
 def pw_cache_pending() -> bool:

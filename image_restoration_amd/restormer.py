@@ -21,7 +21,6 @@ from typing import List, Optional, Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 
@@ -61,6 +60,24 @@ def _apply(fn, *args):
 
 def _grad_mode() -> bool:
     return getattr(_tls, "grad", True)
+
+
+def _use_torch_ops(x: Tensor) -> bool:
+    """The torch.library custom ops (torch_ops.py) are the modules' default door to the kernels; MI_TORCH_OPS=0 selects the bare
+    autograd.Function nodes below (same implementation underneath)."""
+    return x.is_cuda and ops.env("MI_TORCH_OPS") != "0"
+
+
+def _torch_ops():
+    from . import torch_ops
+    return torch_ops
+
+
+def block_apply(x: Tensor, heads: int, params) -> Tensor:
+    """One TransformerBlock / EncoderBlock with autograd: through mi_restore::transformer_block (default) or _BlockFn."""
+    if _use_torch_ops(x):
+        return _torch_ops().transformer_block(x, heads, params)
+    return _apply(_BlockFn, x, heads, *params)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -131,77 +148,105 @@ class _FeedForwardFn(torch.autograd.Function):
         return (dx,) + tuple(None if acc else g for g in grads)
 
 
+def _block_plan(x: Tensor, heads: int, params, need: bool) -> dict:
+    """Which fused forms a block's two halves take (shape / dtype / switches only: also what the custom op's fake
+    implementation reads).  Half-blocks whose backward can end in the one-launch tail (weight gradient + W^T dY + LayerNorm
+    backward + residual add, csrc/bwd_tail.hip) rebuild LN(x) from x and the statistics, so its output is not kept - and where
+    the first 1x1 conv can normalise its input as it loads it (mi_*_fwd_ln) it is never written at all."""
+    n1, att, ffn = params[0:2], params[2:9], params[11:17]
+    wb = n1[1] is not None
+    ks_a, hidden, ks_f = att[3].shape[-1], ffn[4].shape[1], ffn[2].shape[-1]
+    tail_ok = need and wb and not ops.env("MI_NO_BWD_TAIL")                                # (A/B switches)
+    tail_a = bool(tail_ok and ops.mdta_bwd_ln_ok(x, heads, ks_a, att[2] is not None))
+    tail_f = bool(tail_ok and ops.gdfn_bwd_ln_ok(x, hidden, ks_f, ffn[1] is not None))
+    head_ok = not ops.env("MI_NO_LN_HEAD")
+    return {"wb": wb, "tail_a": tail_a, "tail_f": tail_f,
+            "head_a": bool(head_ok and (tail_a or not need) and ops.mdta_fwd_ln_ok(x, heads, ks_a)),
+            "head_f": bool(head_ok and (tail_f or not need) and ops.gdfn_fwd_ln_ok(x, hidden, ks_f))}
+
+
+def _block_forward(x: Tensor, heads: int, params, need: bool):
+    """x + attn(norm1(x)) ; + ffn(norm2(.))   (Restormer.py:146-150) with both residual adds fused into the producing 1x1 GEMM
+    epilogues.  -> (out, saved): ``saved`` = [xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f] (entries None where the
+    backward does not need them; all None when ``need`` is False).  Shared by the autograd.Function (_BlockFn) and the
+    torch.library custom op (torch_ops.transformer_block_fwd)."""
+    n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
+    plan = _block_plan(x, heads, params, need)
+    wb = plan["wb"]
+    xn = yn = None
+    if plan["head_a"]:
+        y, sv_a, mean1, rstd1 = ops.mdta_fwd(x, x, att, heads, need, ln=(n1[0], n1[1], need))
+    else:
+        xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
+        y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
+    if plan["head_f"]:
+        out, sv_f, mean2, rstd2 = ops.gdfn_fwd(y, y, ffn, need, ln=(n2[0], n2[1], need))
+    else:
+        yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
+        out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
+    if not need:
+        return out, [None] * 9
+    # (a half-block on the tail keeps no LayerNorm output: that IS the flag the backward reads)
+    return out, [None if plan["tail_a"] else xn, y, None if plan["tail_f"] else yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f]
+
+
+def _block_backward(x: Tensor, saved, dout: Tensor, heads: int, params, grads, acc: bool) -> Tensor:
+    """Backward of _block_forward: dx; parameter gradients are written (acc: accumulated) into ``grads``."""
+    xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f = saved
+    n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
+    g1, ga, g2, gf = grads[0:2], grads[2:9], grads[9:11], grads[11:17]
+    wb = n1[1] is not None
+    dout = dout.contiguous()
+    if yn is None:                     # one-launch tail: weight gradient + W^T dY + LayerNorm backward + residual
+        dy = ops.gdfn_bwd(y, dout, ffn, sv_f, gf, acc, ln=(n2[0], n2[1], mean2, rstd2, dout, g2[0], g2[1]))
+    else:
+        dyn = ops.gdfn_bwd(yn, dout, ffn, sv_f, gf, acc)
+        dy = ops.ln_bwd(dyn, y, n2[0], mean2, rstd2, dout, wb, g2[0], g2[1], acc)
+    if xn is None:
+        return ops.mdta_bwd(x, dy, att, heads, sv_a, ga, acc, ln=(n1[0], n1[1], mean1, rstd1, dy, g1[0], g1[1]))
+    dxn = ops.mdta_bwd(xn, dy, att, heads, sv_a, ga, acc)
+    return ops.ln_bwd(dxn, x, n1[0], mean1, rstd1, dy, wb, g1[0], g1[1], acc)
+
+
 class _BlockFn(torch.autograd.Function):
-    """x + attn(norm1(x)) ; + ffn(norm2(.))   (Restormer.py:146-150) with both residual adds fused into the
-    producing 1x1 GEMM epilogues (forward) and into the LayerNorm backward (backward)."""
+    """The whole TransformerBlock as one autograd node (the implementation under torch_ops.transformer_block, and the direct
+    route with MI_TORCH_OPS=0)."""
 
     N_LN, N_ATT, N_FFN = 2, 7, 6
 
     @staticmethod
     def forward(ctx, x, heads, *params):
-        n1 = params[0:2]
-        att = params[2:9]
-        n2 = params[9:11]
-        ffn = params[11:17]
         need = _grad_mode() and any(ctx.needs_input_grad)
-        wb = n1[1] is not None
-        # Half-blocks whose backward can end in the one-launch tail (weight gradient + W^T dY + LayerNorm backward +
-        # residual add, csrc/bwd_tail.hip) rebuild LN(x) from x and the statistics, so its output is not kept - and where the
-        # first 1x1 conv can normalise its input as it loads it (mi_*_fwd_ln) it is never written at all.
-        ks_a, hidden, ks_f = att[3].shape[-1], ffn[4].shape[1], ffn[2].shape[-1]
-        tail_ok = need and wb and not os.environ.get("MI_NO_BWD_TAIL")                                # (A/B switches)
-        tail_a = tail_ok and ops.mdta_bwd_ln_ok(x, heads, ks_a, att[2] is not None)
-        tail_f = tail_ok and ops.gdfn_bwd_ln_ok(x, hidden, ks_f, ffn[1] is not None)
-        head_ok = not os.environ.get("MI_NO_LN_HEAD")
-        xn = yn = None
-        if head_ok and (tail_a or not need) and ops.mdta_fwd_ln_ok(x, heads, ks_a):
-            y, sv_a, mean1, rstd1 = ops.mdta_fwd(x, x, att, heads, need, ln=(n1[0], n1[1], need))
-        else:
-            xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
-            y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
-        if head_ok and (tail_f or not need) and ops.gdfn_fwd_ln_ok(y, hidden, ks_f):
-            out, sv_f, mean2, rstd2 = ops.gdfn_fwd(y, y, ffn, need, ln=(n2[0], n2[1], need))
-        else:
-            yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)
-            out, sv_f = ops.gdfn_fwd(yn, y, ffn, need)
+        out, saved = _block_forward(x, heads, params, need)
         if need:
-            ctx.tail_a, ctx.tail_f = tail_a, tail_f
-            ctx.heads, ctx.wb = heads, wb
+            ctx.heads = heads
             ctx.mg = _main_grads(params)
             ctx.present = [p is not None for p in params]
-            ctx.save_for_backward(x, None if tail_a else xn, y, None if tail_f else yn, mean1, rstd1, mean2, rstd2,
-                                  sv_a, sv_f, *[p for p in params if p is not None])
+            ctx.save_for_backward(x, *saved, *[p for p in params if p is not None])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, xn, y, yn, mean1, rstd1, mean2, rstd2, sv_a, sv_f, *rest = ctx.saved_tensors
+        x, *rest = ctx.saved_tensors
+        saved, rest = rest[:9], rest[9:]
         it = iter(rest)
         params = tuple(next(it) if pr else None for pr in ctx.present)
         acc = ctx.mg is not None
         grads = ctx.mg if acc else _fresh_grads(params)
-        n1, att, n2, ffn = params[0:2], params[2:9], params[9:11], params[11:17]
-        g1, ga, g2, gf = grads[0:2], grads[2:9], grads[9:11], grads[11:17]
-        dout = dout.contiguous()
-        if ctx.tail_f:
-            dy = ops.gdfn_bwd(y, dout, ffn, sv_f, gf, acc, ln=(n2[0], n2[1], mean2, rstd2, dout, g2[0], g2[1]))
-        else:
-            dyn = ops.gdfn_bwd(yn, dout, ffn, sv_f, gf, acc)
-            dy = ops.ln_bwd(dyn, y, n2[0], mean2, rstd2, dout, ctx.wb, g2[0], g2[1], acc)
-        if ctx.tail_a:
-            dx = ops.mdta_bwd(x, dy, att, ctx.heads, sv_a, ga, acc, ln=(n1[0], n1[1], mean1, rstd1, dy, g1[0], g1[1]))
-        else:
-            dxn = ops.mdta_bwd(xn, dy, att, ctx.heads, sv_a, ga, acc)
-            dx = ops.ln_bwd(dxn, x, n1[0], mean1, rstd1, dy, ctx.wb, g1[0], g1[1], acc)
+        dx = _block_backward(x, saved, dout, ctx.heads, params, grads, acc)
         return (dx, None) + tuple(None if acc else g for g in grads)
 
 
 def _fused_gdfn_pack(holder, like: Tensor, ln_params, ffn_params) -> Tensor:
-    """Packed weight images of the one-launch LN + GDFN kernel, cached on the module and re-packed whenever one of the
-    eight parameters was written (torch bumps ``_version`` on every in-place update, optimizer steps and
-    ``load_state_dict`` included) or replaced."""
+    """Packed weight images of the one-launch LN + GDFN kernel, cached on the module.  The key holds every way the eight
+    parameters can change: their storage (replaced parameters), their version counters (every in-place write torch makes:
+    ``load_state_dict``, ``copy_``, torch optimizers) and ``ops.weights_epoch()`` - the counter the raw-pointer writers of this
+    package bump (``FlatTrainer.optimizer_step`` / ``weights_changed`` / ``load_state_dict``, ``PackedWeights.refresh``): the fused
+    AdamW kernel updates the flat parameter buffer without touching any version counter (a train -> validate ->
+    train -> validate loop ran every later validation's second half-block on the first validation's weights)."""
     ps = tuple(ln_params) + tuple(ffn_params)
-    key = tuple((p.data_ptr(), p._version) if p is not None else None for p in ps) + (like.shape[2], like.shape[3])
+    key = (tuple((p.data_ptr(), p._version) if p is not None else None for p in ps) + (like.shape[2], like.shape[3])
+           + (ops.weights_epoch(),))
     cache = getattr(holder, "_fg_pack", None)
     if cache is None or cache[0] != key:
         cache = (key, ops.gdfn_fused_pack(like, ln_params[0], ln_params[1], tuple(ffn_params)))
@@ -258,6 +303,12 @@ def fp8_calibrate(model, samples: Sequence[Tensor]) -> None:
             win = b.ffn.project_in.weight.detach()
             wfold = float((win.reshape(win.shape[0], -1) * b.norm2.body.weight.detach()[None, :]).abs().max())
             b._f8["ffn_fused"] = (_f8_pow2(math.sqrt(win.shape[1])), _f8_pow2(wfold), b._f8["ffn"][2], b._f8["ffn"][3])
+        b._f8_key = _f8_weights_key(b)
+
+
+def _f8_weights_key(block):
+    """What the fp8 scales of a block were derived from: the parameters' version counters and the raw-pointer update epoch."""
+    return (ops.weights_epoch(), sum(p._version for p in block.parameters()))
 
 
 def fp8_projections(model, mode: Optional[str]) -> None:
@@ -301,8 +352,12 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
     wb = n1[1] is not None
     heads = block.attn.num_heads
     mode = getattr(block, "_f8_mode", None) if x.dtype == torch.bfloat16 else None
+    if mode and getattr(block, "_f8_key", None) != _f8_weights_key(block):
+        raise RuntimeError("fp8 projections: the weights changed since fp8_calibrate(model, samples) derived the scales "
+                           "(an optimizer step, load_state_dict or an in-place write); calibrate again or switch fp8 off "
+                           "with fp8_projections(model, None)")
     ks_a = att[3].shape[-1]
-    ln_a = ops.mdta_fwd_ln_ok(x, heads, ks_a) and not os.environ.get("MI_NO_LN_HEAD")        # norm1 inside the qkv GEMM
+    ln_a = ops.mdta_fwd_ln_ok(x, heads, ks_a) and not ops.env("MI_NO_LN_HEAD")        # norm1 inside the qkv GEMM
     f8_a = block._f8["attn"] if mode and ops.mdta_fwd_f8_ok(x, heads, ks_a, bool(ln_a)) else None
     if mode:
         F8_COUNTS["f8" if f8_a else "bf16"] += 2
@@ -315,11 +370,11 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
         y = y if f8_a else y[0]
     hidden, ks = ffn[4].shape[1], ffn[2].shape[-1]
     if mode == "all":
-        if (ops.gdfn_fused_ok(y, hidden, ks) and "ffn_fused" in block._f8 and not os.environ.get("MI_NO_FUSED_INFER")
-                and not os.environ.get("MI_FG_CFG")):
+        if (ops.gdfn_fused_ok(y, hidden, ks) and "ffn_fused" in block._f8 and not ops.env("MI_NO_FUSED_INFER")
+                and not ops.env("MI_FG_CFG")):
             F8_COUNTS["f8"] += 2                                                          # the one-launch half-block on fp8 operands
             return ops.gdfn_fused_fwd(y, _fused_gdfn_pack(block, y, n2, ffn), hidden, wb, f8=block._f8["ffn_fused"])[0]
-        ln_f = ops.gdfn_fwd_ln_ok(y, hidden, ks) and not os.environ.get("MI_NO_LN_HEAD")
+        ln_f = ops.gdfn_fwd_ln_ok(y, hidden, ks) and not ops.env("MI_NO_LN_HEAD")
         if ops.gdfn_fwd_f8_ok(y, hidden, ks, bool(ln_f)):
             F8_COUNTS["f8"] += 2
             if ln_f:
@@ -328,7 +383,7 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
             return ops.gdfn_fwd(yn, y, ffn, False, f8=block._f8["ffn"])
     if mode:
         F8_COUNTS["bf16"] += 2
-    if ops.gdfn_fused_ok(y, hidden, ks) and not os.environ.get("MI_NO_FUSED_INFER"):      # (A/B switch)
+    if ops.gdfn_fused_ok(y, hidden, ks) and not ops.env("MI_NO_FUSED_INFER"):      # (A/B switch)
         pack = _fused_gdfn_pack(block, y, n2, ffn)
         out, _, _ = ops.gdfn_fused_fwd(y, pack, hidden, wb, want_stats=False)
         return out
@@ -424,6 +479,13 @@ class _Conv1x1Fn(torch.autograd.Function):
         return dx1, dx2, (None if acc else dw), db
 
 
+def _conv1x1_module(x1: Tensor, x2: Optional[Tensor], conv: nn.Conv2d) -> Tensor:
+    """``conv(torch.cat([x1, x2], 1))`` for a 1x1 conv module, concat-free, with the module's forward hooks run."""
+    y = _apply(_Conv1x1Fn, x1, x2, conv.weight, conv.bias)
+    _fire_forward_hooks(conv, (x1, x2), y)
+    return y
+
+
 def _dgrad_panel(dy: Tensor, w2: Tensor, k0: int, k: int) -> Tensor:
     """dx[:, k0:k0+k] = W[:, k0:k0+k]^T dy  using the column block in place (row stride stays K1+K2)."""
     import ctypes as C
@@ -504,6 +566,8 @@ class LayerNorm(nn.Module):
         return self.body.weight, getattr(self.body, "bias", None)
 
     def forward(self, x):
+        if _use_torch_ops(x):
+            return _torch_ops().layernorm(x, *self._params())
         return _apply(_LayerNormFn, x, *self._params())
 
 
@@ -523,6 +587,8 @@ class FeedForward(nn.Module):
                 self.project_out.weight, self.project_out.bias)
 
     def forward(self, x):
+        if _use_torch_ops(x):
+            return _torch_ops().gdfn(x, self._params())
         return _apply(_FeedForwardFn, x, *self._params())
 
 
@@ -542,6 +608,8 @@ class Attention(nn.Module):
                 self.project_out.weight, self.project_out.bias)
 
     def forward(self, x):
+        if _use_torch_ops(x):
+            return _torch_ops().mdta(x, self.num_heads, self._params())
         return _apply(_AttentionFn, x, self.num_heads, *self._params())
 
 
@@ -559,7 +627,7 @@ class TransformerBlock(nn.Module):
         params = self.norm1._params() + self.attn._params() + self.norm2._params() + self.ffn._params()
         if not torch.is_grad_enabled() and x.is_cuda:
             return _block_infer(self, x, params)
-        return _apply(_BlockFn, x, self.attn.num_heads, *params)
+        return block_apply(x, self.attn.num_heads, params)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -586,7 +654,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             # The weight gradient needs the 9-plane expansion of x again.  Default: keep it from the forward (1.6 GB at bs 32 over the
             # three Upsample convs of Restormer base).  MI_CONV3_RECOL=1: the memory-lean form - for a wide input keep x only and
             # rebuild the expansion in backward (three more im2col launches per step, ~0.9 ms).
-            ctx.recol = ctx.small_in and cin > 4 and bool(os.environ.get("MI_CONV3_RECOL"))
+            ctx.recol = ctx.small_in and cin > 4 and bool(ops.env("MI_CONV3_RECOL"))
             ctx.save_for_backward(x if ctx.recol else saved, weight)
             ctx.has_bias = bias is not None
             ctx.mg = _main_grads((weight, bias))
@@ -621,24 +689,28 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw.contiguous(), db, dres
 
 
-def _conv2d(x: Tensor, conv: nn.Conv2d, residual: Optional[Tensor] = None) -> Tensor:
-    """U-Net glue convolution (dense 3x3): native (_Conv3x3Fn) on rows of 16..256 pixels (power of
-    two); other plane shapes fall back to the PyTorch-ROCm op."""
-    if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 and x.is_cuda
-            and ops.glue3x3_ok(x.shape[2], x.shape[3]) and x.is_contiguous()):
-        return _apply(_Conv3x3Fn, x, conv.weight, conv.bias, residual)
-    y = _conv2d_torch(x, conv)
-    return y if residual is None else y + residual
+def _fire_forward_hooks(module: nn.Module, inputs, output) -> None:
+    """Modules this package uses functionally (their weights are read, ``module(x)`` is never called: the dense 3x3 glue convs,
+    ``reduce_chan_*``, ``up2_1``) still run their registered forward hooks, so observers - the trainer's per-stage gradient
+    bucketing above all - see that the module took part in the step."""
+    if module._forward_hooks:
+        for hook in list(module._forward_hooks.values()):
+            hook(module, inputs, output)
 
 
-def _conv2d_torch(x: Tensor, conv: nn.Conv2d) -> Tensor:
-    """U-Net glue convolution (dense 3x3): SURVEY 8(f) row f1 ("next"), still a PyTorch-ROCm op this round.
-    Parameters stay fp32; they are cast to the activation dtype for the call."""
-    w = conv.weight if conv.weight.dtype == x.dtype else conv.weight.to(x.dtype)
-    b = conv.bias
-    if b is not None and b.dtype != x.dtype:
-        b = b.to(x.dtype)
-    return F.conv2d(x, w, b, conv.stride, conv.padding)
+def _conv2d(x: Tensor, conv: nn.Conv2d, residual: Optional[Tensor] = None, owner: Optional[nn.Module] = None) -> Tensor:
+    """U-Net glue convolution (dense 3x3, stride 1, pad 1: SURVEY 8(f) row f1) on the native kernels (_Conv3x3Fn); rows of
+    16..256 pixels (power of two) take the wave-streaming layout kernels, every other plane the general form.  Anything else
+    (another kernel size / stride / groups, a CPU tensor) raises: no vendor convolution runs on this path."""
+    if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1
+            and conv.dilation == (1, 1)):
+        raise NotImplementedError("image_restoration_amd: only the dense 3x3 / stride 1 / pad 1 glue convolution is built "
+                                  f"(got kernel {conv.kernel_size}, stride {conv.stride}, padding {conv.padding}, "
+                                  f"groups {conv.groups})")
+    ops._gpu(x, residual)
+    y = _apply(_Conv3x3Fn, x, conv.weight, conv.bias, residual)
+    _fire_forward_hooks(owner if owner is not None else conv, (x,), y)
+    return y
 
 
 class _PixelShuffleFn(torch.autograd.Function):
@@ -685,11 +757,8 @@ class _UpCatFn(torch.autograd.Function):
 
 
 def _shuffle(x: Tensor, unshuffle: bool) -> Tensor:
-    V = 8 if x.dtype == torch.bfloat16 else 4
-    w_lo = x.shape[3] // 2 if unshuffle else x.shape[3]
-    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and w_lo % V == 0 and x.is_contiguous():
-        return _apply(_PixelShuffleFn, x, unshuffle)
-    return (F.pixel_unshuffle(x, 2) if unshuffle else F.pixel_shuffle(x, 2)).contiguous()
+    ops._gpu(x)
+    return _apply(_PixelShuffleFn, x, unshuffle)
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -729,11 +798,9 @@ class Upsample(nn.Module):
 
 def _up_cat(up: "Upsample", x: Tensor, skip: Tensor) -> Tensor:
     """torch.cat([up(x), skip], 1) (Restormer.py:265-266) with the shuffle writing into the concatenation buffer."""
-    z = _conv2d(x, up.body[0])
-    V = 8 if z.dtype == torch.bfloat16 else 4
-    if z.is_cuda and z.dtype in (torch.bfloat16, torch.float32) and z.shape[3] % V == 0 and skip.is_contiguous():
-        return _apply(_UpCatFn, z, skip)
-    return torch.cat([F.pixel_shuffle(z, 2), skip], 1)
+    z = _conv2d(x, up.body[0], owner=up)
+    ops._gpu(skip)
+    return _apply(_UpCatFn, z, skip)
 
 
 def _stage(dim, heads, n, ffn, bias, ln):
@@ -779,17 +846,14 @@ class Restormer(nn.Module):
         latent = self.latent(self.down3_4(out_enc_level3))
 
         # concat-free channel reduce: two K-panels of one 1x1 GEMM (Restormer.py:259-261)
-        inp_dec_level3 = _apply(_Conv1x1Fn, self.up4_3(latent), out_enc_level3, self.reduce_chan_level3.weight,
-                                          self.reduce_chan_level3.bias)
+        inp_dec_level3 = _conv1x1_module(self.up4_3(latent), out_enc_level3, self.reduce_chan_level3)
         out_dec_level3 = self.decoder_level3(inp_dec_level3)
-        inp_dec_level2 = _apply(_Conv1x1Fn, self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2.weight,
-                                          self.reduce_chan_level2.bias)
+        inp_dec_level2 = _conv1x1_module(self.up3_2(out_dec_level3), out_enc_level2, self.reduce_chan_level2)
         out_dec_level2 = self.decoder_level2(inp_dec_level2)
         inp_dec_level1 = _up_cat(self.up2_1, out_dec_level2, out_enc_level1)
         out_dec_level1 = self.refinement(self.decoder_level1(inp_dec_level1))
 
         if self.dual_pixel_task:
-            out_dec_level1 = out_dec_level1 + _apply(_Conv1x1Fn, inp_enc_level1, None, self.skip_conv.weight,
-                                                               self.skip_conv.bias)
+            out_dec_level1 = out_dec_level1 + _conv1x1_module(inp_enc_level1, None, self.skip_conv)
             return _conv2d(out_dec_level1, self.output)
         return _conv2d(out_dec_level1, self.output, inp_img)

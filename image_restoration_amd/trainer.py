@@ -79,10 +79,20 @@ class FlatTrainer:
         # start that much earlier and leave only the patch embedding behind the last one); flat ranges are contiguous
         # by construction (parameters() order = registration order)
         self.stages: List[Tuple[str, nn.Module, int, int]] = []
+
+        def units_of(name, mod):
+            # a ModuleList has no forward: its forward hook would never fire, so its ELEMENTS are the stages (recursively:
+            # MoCE-IR's enc / dec are ModuleLists of ModuleLists); an nn.Sequential of blocks becomes one stage per block
+            if isinstance(mod, nn.ModuleList):
+                out = []
+                for i, sub in enumerate(mod):
+                    out += units_of(f"{name}.{i}", sub)
+                return out
+            if bucket_blocks and isinstance(mod, nn.Sequential) and len(mod) > 1:
+                return [(f"{name}.{i}", sub) for i, sub in enumerate(mod)]
+            return [(name, mod)]
         for name, child in model.named_children():
-            units = [(f"{name}.{i}", sub) for i, sub in enumerate(child)] if (bucket_blocks and isinstance(child, nn.Sequential)
-                                                                             and len(child) > 1) else [(name, child)]
-            for uname, unit in units:
+            for uname, unit in units_of(name, child):
                 ps = [p for p in unit.parameters() if p.requires_grad]
                 if not ps:
                     continue
@@ -95,6 +105,12 @@ class FlatTrainer:
         self._reduced: set = set()
         self._works = []
         self._comm_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self._comm) else None
+        # a stage may be declared ready early ("did not run this step") only if it would have fired a forward hook had it
+        # run: true for modules with a forward of their own; containers that only hold parameters are left to
+        # reduce_gradients()
+        self._hookable = [type(child).forward is not nn.Module.forward and not isinstance(child, (nn.ModuleList, nn.ModuleDict,
+                                                                                                nn.ParameterList, nn.ParameterDict))
+                          for _, child, _, _ in self.stages]
         if self.overlap:
             for idx, (_, child, _, _) in enumerate(self.stages):
                 child.register_forward_hook(self._make_fwd_hook(idx))
@@ -109,7 +125,7 @@ class FlatTrainer:
         self._next = len(self.stages) - 1
         self._bwd_started = False
         if self._pack_cache:
-            ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat_p)
+            self._cache_token = ops.pw_cache_enable(int(total) * 8 + (4 << 20), dev, self.flat_p)
             # Anything that writes the parameters other than optimizer_step (load_state_dict to resume or to evaluate a
             # checkpoint, an EMA copy-back, a manual re-init) must not leave the GEMMs on stale packed images: torch bumps
             # a parameter's version counter on every in-place write, the fused AdamW kernel (a raw pointer write) does
@@ -129,6 +145,7 @@ class FlatTrainer:
     def weights_changed(self) -> None:
         """Tell the trainer the parameters were written outside optimizer_step (called automatically after
         load_state_dict and whenever the flat buffer's version counter moved)."""
+        ops.bump_weights_epoch()      # caches of weight-derived data outside the library (fused-kernel packs, fp8 scales)
         if self._pack_cache:
             ops.pw_cache_refresh()
             self._p_version = self._weights_version()
@@ -138,9 +155,11 @@ class FlatTrainer:
             self.weights_changed()
 
     def close(self) -> None:
-        """Detach the library's packed-weight cache from this trainer's buffers (the cache is process-global)."""
+        """Detach the library's packed-weight cache from this trainer's buffers.  The cache is process-global: it is switched
+        off only if it still belongs to this trainer (a trainer or PackedWeights made later keeps its own)."""
         if self._pack_cache:
-            ops.pw_cache_enable(0, self.flat_p.device, None)
+            ops.pw_cache_release(getattr(self, "_cache_token", None))
+            self._cache_token = None
             self._pack_cache = False
 
     def __del__(self):
@@ -225,10 +244,15 @@ class FlatTrainer:
                 # (Holds for the chain-shaped top level of Restormer / MoCE-IR / AdaIR, where a later stage consumes an
                 # earlier one's output; skip connections only ADD consumers that ran later still.)
                 if not self._bwd_started:
-                    # stages that did not run this step (an expert nobody routed to) have nothing more to wait for
+                    # Stages whose forward hook did not fire this step did not run (an optional branch): nothing will ever be
+                    # written into their slice, so they are ready from the start.  This is sound only because every stage that
+                    # DOES run fires its hook: ModuleList containers are expanded into their elements (units_of above) and the
+                    # modules this package uses functionally (glue convs, reduce_chan, up2_1) run their hooks explicitly
+                    # (restormer._fire_forward_hooks).  A stage that cannot fire one (a parameter used outside any module
+                    # forward) is left to reduce_gradients(): see _hookable.
                     self._bwd_started = True
                     for i in range(len(self.stages)):
-                        if i not in self._seen_fwd:
+                        if i not in self._seen_fwd and self._hookable[i]:
                             self._mark_ready(i)
                 for later in self._exec_order[pos + 1:]:
                     self._mark_ready(later)
@@ -290,6 +314,7 @@ class FlatTrainer:
 
     def optimizer_step(self, use_dev_scalars: bool = False) -> None:
         self.step_count += 1
+        ops.bump_weights_epoch()      # the fused AdamW kernel writes the parameters without bumping any version counter
         scale = 1.0 / self.world
         if self.sharded:
             lo = self.rank * self.shard

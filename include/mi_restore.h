@@ -45,6 +45,9 @@ enum {
 
 int mi_version(void);
 const char* mi_last_error(void);
+/* The MI_* A/B switches (environment variables consulted by the launch planners) are read once, at first use.  This re-reads
+ * them: for tests and A/B tools that flip a switch inside one process.  Not meant to race with launches on other threads. */
+int mi_env_reload(void);
 
 /* ------------------------------------------------------------------------
  * Channel LayerNorm on NCHW  (Restormer.py:25-70; moce_ir.py:156-221;
@@ -432,7 +435,8 @@ int mi_gelu_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtyp
 int mi_gelu_gap_bwd(const void* x, const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream);
 
 /* Gating products of the expert path: op 0  out = a * b  (FFTAttention `out * v`, moce_ir.py:419);
- * op 1  out = a * silu(b)  (ModExpert `body(x) * silu(proj[1](shared))`, :555).  bwd writes da and db. */
+ * op 1  out = a * silu(b)  (ModExpert `body(x) * silu(proj[1](shared))`, :555);  op 2  out = gelu_erf(a), b unused
+ * (FrequencyEmbedding's MLP activation, :1071).  bwd writes da and db (op 2: da only). */
 /* a, b (and da, db) are [rows][L] with row strides in elements (0 = L); out and dout are contiguous [rows][L]. */
 int mi_ewise_fwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, void* out, int64_t rows, int64_t L, int op, int dtype,
                  void* stream);
@@ -447,7 +451,8 @@ int mi_ewise_bwd(const void* a, int64_t a_rs, const void* b, int64_t b_rs, const
  *   col2im3x3: z[B,9M,H,W] -> y[B,M,H,W],  y[m][y][x] = sum_taps z[m*9+ky*3+kx][y+ky-1][x+kx-1] (+ bias[m]) (+ residual);
  *              flip != 0 negates the shifts (scatter of the transposed convolution: input gradient of the im2col form).
  * conv(x;W) = W[Cout,9Cin] . im2col(x) when Cin is tiny; = col2im(Wz[9Cout,Cin] . x) when Cout is tiny.
- * Rows of 16..256 pixels, power of two (mi_glue3x3_ok).
+ * Any H, W: rows of 16..256 pixels (power of two) on 16-byte aligned planes take the wave-streaming forms, everything
+ * else an element-wise general form (mi_glue3x3_ok: H, W >= 1).
  * ------------------------------------------------------------------------ */
 int mi_glue3x3_ok(int H, int W);
 int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip, int dtype, void* stream);

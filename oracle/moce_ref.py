@@ -162,3 +162,57 @@ def frequency_embedding(x: Tensor, sd: Dict[str, Tensor]) -> Tensor:
     h = F.gelu(F.conv2d(x, sd["high_conv.0.conv.weight"], None, padding=1, groups=c)).mean(dim=(-2, -1))
     h = F.gelu(F.linear(h, sd["mlp.0.weight"], sd["mlp.0.bias"]))
     return F.linear(h, sd["mlp.2.weight"], sd["mlp.2.bias"])
+
+
+def expert_complexity(sd: Dict[str, Tensor], prefix: str, num_experts: int, scale: str = "max") -> Tensor:
+    """AdapterLayer's `complexity` buffer (moce_ir.py:653, RoutingFunction.__init__ :713-724): the experts' parameter counts,
+    normalised by the largest ("max") or smallest ("min").  Computed in fp32 like the reference's buffer."""
+    counts = [sum(v.numel() for k, v in sd.items() if k.startswith(f"{prefix}experts.{e}.")) for e in range(num_experts)]
+    c = torch.tensor(counts, dtype=torch.float32)
+    return c / (c.max() if scale == "max" else c.min())
+
+
+def moceir_forward(img: Tensor, sd: Dict[str, Tensor], cfg: dict, noise: Tensor, training: bool):
+    """MoCEIR.forward (moce_ir.py:1207-1231) -> (restored, total_loss): patch embedding (3x3, :1209), encoder groups of
+    EncoderBlocks + Downsample (3x3 C -> C/2, PixelUnshuffle(2), :1013-1028) (:1213-1216), latent group, FrequencyEmbedding of
+    the latent features (:1218-1219), per decoder stage Upsample (3x3 C -> 2C, PixelShuffle(2), :1031-1042) -> cat with the
+    skip -> 1x1 fusion -> DecoderBlocks whose auxiliary losses are summed (:1221-1225), refinement group, 3x3 output conv +
+    input (:1227-1228), total_loss / sum(num_dec_blocks) (:1230).
+    cfg: dim, levels, heads, num_blocks, num_dec_blocks, num_refinement_blocks, rank, num_experts, rank_type, topk,
+    with_complexity, complexity_scale.  `noise` [B, E] is the N(0,1) draw every router adds (the tests inject one seeded draw
+    for all decoder blocks, exactly as the golden capture patched torch.randn_like)."""
+    levels, heads = cfg["levels"], list(cfg["heads"])
+    nb, ndb = list(cfg["num_blocks"]), list(cfg["num_dec_blocks"])
+    E = cfg["num_experts"]
+    dt = img.dtype
+
+    def group(x, prefix, n, hd):
+        for j in range(n):
+            x = encoder_block(x, sub_state(sd, f"{prefix}layers.{j}."), hd)
+        return x
+
+    feats = F.conv2d(img, sd["patch_embed.proj.weight"], None, padding=1)
+    skips = []
+    for i in range(levels - 1):
+        feats = group(feats, f"enc.{i}.0.", nb[i], heads[i])
+        skips.append(feats)
+        feats = F.pixel_unshuffle(F.conv2d(feats, sd[f"enc.{i}.1.body.0.weight"], None, padding=1), 2)
+    feats = group(feats, "latent.", nb[-1], heads[-1])
+    freq_emb = frequency_embedding(feats, sub_state(sd, "freq_embed."))
+    total = 0
+    rheads, rndb = heads[::-1], ndb[::-1]
+    for j in range(levels - 1):
+        dim = cfg["dim"] * 2 ** (levels - 2 - j)
+        feats = F.pixel_shuffle(F.conv2d(feats, sd[f"dec.{j}.0.body.0.weight"], None, padding=1), 2)
+        feats = F.conv2d(torch.cat([feats, skips.pop()], dim=1), sd[f"dec.{j}.1.weight"], sd.get(f"dec.{j}.1.bias"))
+        for b in range(rndb[j]):
+            pre = f"dec.{j}.2.layers.{b}."
+            bsd = sub_state(sd, pre)
+            acfg = dict(dim=dim, rank=cfg["rank"], num_experts=E, top_k=cfg["topk"], rank_type=cfg["rank_type"],
+                        with_complexity=cfg.get("with_complexity", False),
+                        complexity=expert_complexity(bsd, "adapter.", E, cfg.get("complexity_scale", "max")).to(dt))
+            feats, aux = decoder_block(feats, freq_emb, bsd, rheads[j + 1], acfg, noise, training)
+            total = total + aux
+    feats = group(feats, "refinement.", cfg["num_refinement_blocks"], heads[0])
+    out = F.conv2d(feats, sd["output.weight"], sd.get("output.bias"), padding=1) + img
+    return out, total / sum(ndb)

@@ -21,3 +21,28 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _mi_env_follows_monkeypatch(monkeypatch):
+    """The library and the package read their MI_* A/B switches once (mi_env_reload / image_restoration_amd.reload_env re-read
+    them): every monkeypatch.setenv / delenv inside a test, and the restore at its end, is followed by a reload, so the tests
+    keep flipping switches per call as before."""
+    def reload():
+        mod = sys.modules.get("image_restoration_amd")
+        if mod is not None and hasattr(mod, "reload_env"):
+            mod.reload_env()
+
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        orig_set(name, value, prepend)
+        reload()
+
+    def delenv(name, raising=True):
+        orig_del(name, raising)
+        reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()          # restore the environment now (idempotent: monkeypatch's own teardown finds nothing left) ...
+    reload()                    # ... and let the library see it

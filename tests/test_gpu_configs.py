@@ -1,0 +1,219 @@
+"""The BASELINE.json configurations themselves against the CPU oracle (round-2 verdict: "put the BASELINE configs under -m gpu"):
+
+  C2  Restormer base (Restormer.py ctor defaults), whole network, forward + L1 backward: output, input gradient and the gradient
+      norm of every parameter vs oracle.restormer_forward (fp32 activations and bf16 activations).
+  C4  MoCE-IR base (MoCE-IR-main/src/options.py:70-84: dim 48, blocks [4,6,6,8], dec blocks [2,4,4], 4 experts, top-1, spread ranks),
+      one training step's forward / backward at B = 2, 128^2 with an injected router noise draw vs oracle.moce_ref.moceir_forward
+      (pinned on the reference-captured whole-network golden by tests/test_oracle_golden_moce.py): output, auxiliary loss, loss,
+      every parameter-gradient norm.
+  C5  inference.tiled_restore on Restormer base at 1 x 3 x 1024^2, bf16 and fp8 ("all" four projections): output cells vs the
+      oracle run on that cell's padded 256^2 window, with a stated PSNR bar for each precision (NOT fp8-vs-own-bf16).
+
+The oracle legs run on the GPU box's host cores (a few seconds each).  Weights: seeded (oracle.make_state), as everywhere.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import moce_ref as MR
+from oracle import restormer_ref as R
+from oracle.fixtures import seeded_input
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(got, ref):
+    ref = ref.detach().cpu().double()
+    return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def psnr_between(a, b):
+    mse = float(((a.detach().cpu().double() - b.detach().cpu().double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+def _image(shape, seed):
+    """A smooth synthetic 'photograph' in [0,1] (low-frequency waves + a little texture): clean target of the sigma = 25 recipe."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    img = torch.zeros(shape)
+    for b in range(B):
+        for c in range(C):
+            f = torch.rand(4, generator=g) * 6 + 1
+            ph = torch.rand(4, generator=g) * 6.28
+            img[b, c] = 0.5 + 0.2 * torch.sin(f[0] * 6.28 * xx + ph[0]) * torch.cos(f[1] * 6.28 * yy + ph[1]) \
+                + 0.15 * torch.sin(f[2] * 6.28 * (xx + yy) + ph[2]) + 0.05 * torch.sin(40 * f[3] * xx * yy + ph[3])
+    return (img + 0.02 * torch.randn(shape, generator=g)).clamp(0, 1)
+
+
+class injected_noise:
+    """Every torch.randn_like inside the block returns one seeded draw (what the golden capture did to the reference's router)."""
+
+    def __init__(self, seed):
+        self.seed = seed
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        seed = self.seed
+        torch.randn_like = lambda t, **kw: seeded_input(tuple(t.shape), seed, torch.float64).to(t.dtype).to(t.device)
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
+def _grad_norm_report(named_grads, ref_grads, tol, floor_scale):
+    """Every parameter's gradient norm within tol of the oracle's (relative), with an absolute floor for gradients that are
+    themselves round-off sized (floor_scale x the largest gradient norm of the network)."""
+    biggest = max(float(g.norm()) for g in ref_grads.values() if g is not None)
+    worst = ("", 0.0)
+    for name, g in named_grads.items():
+        r = ref_grads.get(name)
+        rn = float(r.norm()) if r is not None else 0.0
+        gn = float(g.norm()) if g is not None else 0.0
+        err = abs(gn - rn) / max(rn, floor_scale * biggest)
+        if err > worst[1]:
+            worst = (name, err)
+    assert worst[1] < tol, worst
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ C2
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 3e-4, 3e-3), (torch.bfloat16, 3e-2, 8e-2)])
+def test_c2_restormer_base_forward_backward_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE configs[1] network (Restormer base, 26.13 M parameters), whole: 1 x 3 x 128^2 degraded -> restored, L1 loss
+    against the clean target, backward.  fp32 activations (exact-fp32 MFMA path): output 3e-4, every gradient norm 3e-3 of the
+    fp64 oracle; bf16 activations (the training configuration): 3e-2 / 8e-2 (storage rounding through 44 blocks)."""
+    import image_restoration_amd as m
+    cfg = R.RESTORMER_BASE
+    sd = R.make_restormer_state(cfg, seed=21)
+    net = m.Restormer(**cfg)
+    net.load_state_dict(sd)
+    assert sum(p.numel() for p in net.parameters()) == 26126644
+    net = net.to(DEV).train()
+    clean = _image((1, 3, 128, 128), 210)
+    degraded = R.degrade_sigma(clean, 25.0, 211)
+    x = degraded.to(DEV).to(dtype).requires_grad_(True)
+    y = net(x)
+    loss = (y.float() - clean.to(DEV)).abs().mean()
+    loss.backward()
+    # oracle, fp64, on the same (dtype-rounded) input
+    xr = x.detach().double().cpu().requires_grad_(True)
+    ps = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    yr = R.restormer_forward(xr, ps, cfg)
+    lr = (yr - clean.double()).abs().mean()
+    lr.backward()
+    assert rel(y, yr) < tol_y, ("y", rel(y, yr))
+    assert abs(float(loss) - float(lr)) < tol_y * max(float(lr), 1e-3), (float(loss), float(lr))
+    assert abs(R.psnr(y.float().cpu(), clean) - R.psnr(yr.float(), clean)) < (0.01 if dtype == torch.float32 else 0.1)
+    assert rel(x.grad, xr.grad) < 10 * tol_y, ("dx", rel(x.grad, xr.grad))
+    worst = _grad_norm_report({n: p.grad for n, p in net.named_parameters()}, {k: v.grad for k, v in ps.items()}, tol_g, 1e-4)
+    print(f"C2 {dtype}: y {rel(y, yr):.2e}, dx {rel(x.grad, xr.grad):.2e}, worst grad norm {worst}")
+
+
+# ------------------------------------------------------------------------------------------------ C4
+MOCEIR_BASE = dict(dim=48, num_blocks=[4, 6, 6, 8], num_dec_blocks=[2, 4, 4], levels=4, heads=[1, 2, 4, 8],
+                   num_refinement_blocks=4, topk=1, num_experts=4, rank=2, with_complexity=True, depth_type="constant",
+                   stage_depth=[1, 1, 1], rank_type="spread", complexity_scale="max")
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 5e-4, 5e-3), (torch.bfloat16, 4e-2, 1e-1)])
+def test_c4_moceir_base_train_step_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE configs[3] network (MoCE-IR base, 25.35 M parameters): forward + (L1 + 0.01 aux) backward of one training step at
+    B = 2, 128^2 (train.py:62-71) with the router's noise draw injected.  Same routing as the oracle (asserted through the
+    auxiliary loss and the set of experts that received gradients), output, loss, every parameter-gradient norm."""
+    import image_restoration_amd.moce_ir as mo
+    net = mo.MoCEIR(**MOCEIR_BASE)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items() if not k.endswith("complexity")}
+    sd = R.make_state(shapes, 41)
+    net.load_state_dict(sd, strict=False)
+    net = net.to(DEV).train()
+    B = 2
+    clean = _image((B, 3, 128, 128), 410)
+    x = R.degrade_sigma(clean, 25.0, 411).to(DEV).to(dtype).requires_grad_(True)
+    with injected_noise(412):
+        y = net(x)
+        loss = (y.float() - clean.to(DEV)).abs().mean() + 0.01 * net.total_loss
+        loss.backward()
+    xr = x.detach().float().cpu().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr, total_r = MR.moceir_forward(xr, ps, MOCEIR_BASE, seeded_input((B, 4), 412, torch.float64).float(), True)
+    lr = (yr - clean).abs().mean() + 0.01 * total_r
+    lr.backward()
+    assert abs(float(net.total_loss) - float(total_r)) < 1e-3 * max(1.0, abs(float(total_r))), (float(net.total_loss), float(total_r))
+    assert rel(y, yr) < tol_y, ("y", rel(y, yr))
+    assert abs(float(loss) - float(lr)) < tol_y * max(float(lr), 1e-3)
+    got = {n: p.grad for n, p in net.named_parameters()}
+    ref = {k: v.grad for k, v in ps.items()}
+    # the same experts were routed to: an expert the oracle left without a gradient has none (or zeros) here
+    for n, r in ref.items():
+        if ".experts." in n and r is None:
+            assert got[n] is None or float(got[n].abs().max()) == 0.0, n
+    worst = _grad_norm_report(got, ref, tol_g, 1e-4)
+    print(f"C4 {dtype}: y {rel(y, yr):.2e}, aux {float(net.total_loss):.5f}/{float(total_r):.5f}, worst grad norm {worst}")
+
+
+# ------------------------------------------------------------------------------------------------ C5
+def _c5_setup():
+    import image_restoration_amd as m
+    cfg = R.RESTORMER_BASE
+    sd = R.make_restormer_state(cfg, seed=51)
+    net = m.Restormer(**cfg)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    clean = _image((1, 3, 1024, 1024), 510)
+    img = R.degrade_sigma(clean, 25.0, 511)
+    return net, sd, cfg, img
+
+
+def _oracle_cells(img, sd, cfg, cells, tile=224, ov=16):
+    """The oracle's restoration of the given output cells: the network on each cell's replicate-padded (tile + 2 ov)^2 window
+    of the bf16-rounded image (what tiled_restore feeds the network), cropped to the cell."""
+    H0, W0 = img.shape[-2:]
+    H, W = -(-H0 // tile) * tile, -(-W0 // tile) * tile
+    xp = F.pad(img.to(torch.bfloat16).float(), (ov, ov + W - W0, ov, ov + H - H0), mode="replicate")
+    size = tile + 2 * ov
+    out = {}
+    with torch.no_grad():
+        for (i, j) in cells:
+            win = xp[:, :, i * tile:i * tile + size, j * tile:j * tile + size].contiguous()
+            out[(i, j)] = R.restormer_forward(win, sd, cfg)[:, :, ov:ov + tile, ov:ov + tile]
+    return out
+
+
+def test_c5_tiled_1024_restormer_base_bf16_and_fp8_vs_oracle():
+    """BASELINE configs[4]: Restormer base, 1 x 3 x 1024^2, tiled_restore (224 + 2 x 16 cells -> 256^2 network inputs, 25 cells),
+    bf16 activations, then fp8 (e4m3) operands in all four 1x1 projections of every block.  Three output cells (a corner, an
+    interior cell, the ragged last row / column) against the fp32 oracle on the cell's own window.  Bars: bf16 >= 40 dB,
+    fp8 >= 34 dB PSNR against the ORACLE output (data range 1); the measured values are printed."""
+    from image_restoration_amd import inference, restormer
+    net, sd, cfg, img = _c5_setup()
+    cells = [(0, 0), (2, 3), (4, 4)]
+    ref = _oracle_cells(img, sd, cfg, cells)
+    tile = 224
+    x = img.to(DEV)
+    out16 = inference.tiled_restore(net, x, tile=tile, overlap=16, tile_batch=25)
+    assert out16.shape == x.shape
+    inference.calibrate_fp8(net, x, tile=tile, overlap=16, max_tiles=8)
+    restormer.fp8_projections(net, "all")
+    restormer.F8_COUNTS["f8"] = restormer.F8_COUNTS["bf16"] = 0
+    try:
+        out8 = inference.tiled_restore(net, x, tile=tile, overlap=16, tile_batch=25)
+    finally:
+        restormer.fp8_projections(net, None)
+    assert restormer.F8_COUNTS["f8"] == 4 * 44 and restormer.F8_COUNTS["bf16"] == 0, restormer.F8_COUNTS   # all 176 projections on fp8
+    report = {}
+    for (i, j), r in ref.items():
+        h, w = min(tile, 1024 - i * tile), min(tile, 1024 - j * tile)
+        r = r[:, :, :h, :w]
+        g16 = out16[:, :, i * tile:i * tile + h, j * tile:j * tile + w].float().cpu()
+        g8 = out8[:, :, i * tile:i * tile + h, j * tile:j * tile + w].float().cpu()
+        report[(i, j)] = (psnr_between(g16, r), psnr_between(g8, r), rel(g16, r), rel(g8, r))
+    print("C5 PSNR vs oracle (bf16, fp8), rel err (bf16, fp8):", report)
+    for cell, (p16, p8, e16, e8) in report.items():
+        assert p16 >= 40.0, (cell, p16)
+        assert p8 >= 34.0, (cell, p8)
+        assert e16 < 5e-2 and e8 < 1.5e-1, (cell, e16, e8)

@@ -62,7 +62,7 @@ def test_draw_batch_plan_stays_inside_images():
     sample, top, left, mode, sig = D.draw_batch_plan(pool, 256, 64, (15.0, 25.0, 50.0), g)
     hw = pool._hw[sample.long()]
     assert bool(((top >= 0) & (top.long() + 64 <= hw[:, 0]) & (left >= 0) & (left.long() + 64 <= hw[:, 1])).all())
-    assert set(mode.tolist()) == set(range(8)) and set(sig.tolist()) == {15.0, 25.0, 50.0}
+    assert set(mode.tolist()) == set(range(1, 8)) and set(sig.tolist()) == {15.0, 25.0, 50.0}
 
 
 @pytest.mark.parametrize("dtype,shape", [(torch.float32, (3, 3, 40, 72)), (torch.bfloat16, (2, 3, 96, 64)), (torch.float32, (1, 1, 7, 9))])

@@ -349,6 +349,9 @@ def test_patch_circconv_vs_fft(p, shape):
     assert rel(ops.patch_circconv(cot.to(DEV), y, p, flip=True), xr.grad) < 2e-5
 
 
+AUX_W = 1.0e4      # weight of the auxiliary loss in the objective of the real-plane test: router gradients comparable to the others
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 4e-2)])
 @pytest.mark.parametrize("dim,heads,hw", [(48, 1, (256, 256)), (96, 2, (128, 128)), (192, 4, (64, 64))])
 def test_decoder_block_at_real_planes_vs_oracle(dtype, tol, dim, heads, hw):
@@ -373,21 +376,29 @@ def test_decoder_block_at_real_planes_vs_oracle(dtype, tol, dim, heads, hw):
     xg = x.to(DEV).to(dtype).requires_grad_(True)
     with injected_noise(3003 + dim):
         out, aux = m(xg, fe.to(DEV))
-    out.backward(cot.to(DEV).to(dtype))
+    # The objective carries the router's auxiliary loss, as the training step does (train.py:62-71).  Through the MAIN path alone
+    # the router weights get NO gradient at top-1: the adapter output of a sample is its expert's output times one gate value, and
+    # it enters CrossAttention as the query, which is L2-normalised per channel row - the gate cancels exactly
+    # (tests/test_oracle_golden_moce.py::test_router_main_path_gradient_is_exactly_zero_at_top1 shows 1e-17 in fp64).  Round 2
+    # compared that round-off-sized "gradient" relatively, saw 120 % and widened a skip threshold; with the aux term the router
+    # gradients are real numbers and every parameter is held to the bound, none skipped.
+    (out.float() * cot.to(DEV)).sum().add(aux.float() * AUX_W).backward()
     # oracle on the same (dtype-rounded) input, fp32 on the host
     cfg = dict(dim=dim, rank=2, num_experts=4, top_k=1, rank_type="spread", with_complexity=True,
                complexity=m.adapter.routing.complexity.cpu().float())
     xr = xg.detach().float().cpu().requires_grad_(True)
     ps = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()}
     ref, aux_r = MR.decoder_block(xr, fe, ps, heads, cfg, seeded_input((B, 4), 3003 + dim), True)
-    ref.backward(cot.to(dtype).float())
+    ((ref * cot).sum() + aux_r * AUX_W).backward()
     assert rel(out, ref) < tol, ("y", rel(out, ref))
     assert rel(xg.grad, xr.grad) < 3 * tol, ("dx", rel(xg.grad, xr.grad))
     assert abs(float(aux) - float(aux_r)) < 1e-3
     worst = ("", 0.0)
     for name, p in m.named_parameters():
         g_ref = ps[name].grad
-        if g_ref is None or float(g_ref.abs().max()) < 1e-5:     # (a saturated router: gradients of 1e-6 are fp32 round-off)
+        assert g_ref is not None or "experts." in name, name                  # only an un-routed expert has no gradient
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
         assert p.grad is not None, name
         e = rel(p.grad, g_ref)

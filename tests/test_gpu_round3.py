@@ -1,0 +1,292 @@
+"""Round-3 GPU checks of the host-side fixes: weight-derived caches follow the fused optimizer, the U-Net
+glue is native on every plane (verdict weak #5), and the torch.library custom ops are the modules' door to the kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restormer_ref as R
+from oracle.fixtures import seeded_input
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def M():
+    import image_restoration_amd as m
+    return m
+
+
+def rel(got, ref):
+    ref = ref.detach().cpu().double()
+    return float((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _train_steps(tr, net, x, n):
+    for _ in range(n):
+        tr.zero_grad()
+        net(x).float().abs().mean().backward()
+        tr.reduce_gradients()
+        tr.optimizer_step()
+
+
+def _fresh_copy(net, like):
+    ref = like()
+    ref.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()})
+    return ref.to(DEV).eval()
+
+
+def test_validation_after_fused_optimizer_steps_uses_current_weights():
+    """train -> no_grad validate -> train -> no_grad validate.  The fused AdamW kernel writes the parameters
+    through raw pointers (no version counter moves); the one-launch LN + GDFN kernel's packed weights (restormer._fused_gdfn_pack)
+    must still be rebuilt.  Every validation output must equal a FRESH module loaded with the current state_dict, bit for bit."""
+    m = M()
+    from image_restoration_amd.trainer import FlatTrainer
+    torch.manual_seed(0)
+    make = lambda: m.TransformerBlock(48, 1, 2.66, False, "WithBias")
+    net = make().to(DEV)
+    tr = FlatTrainer(net, lr=5e-2)
+    x = seeded_input((2, 48, 32, 64), 31).to(DEV).to(torch.bfloat16)
+    try:
+        outs = []
+        for _ in range(3):
+            _train_steps(tr, net, x, 2)
+            net.eval()
+            with torch.no_grad():
+                y = net(x).float()
+            net.train()
+            assert getattr(net, "_fg_pack", None) is not None, "validation did not take the fused GDFN kernel"
+            with torch.no_grad():                         # (a fresh module's weights lie outside the trainer's flat buffer: the
+                want = _fresh_copy(net, make)(x).float()  #  library packs them per call, the trainer's cache is not involved)
+            assert torch.equal(y, want), float((y - want).abs().max())
+            outs.append(y)
+        assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])     # the weights did move
+    finally:
+        tr.close()
+
+
+def test_fp8_scales_refuse_stale_weights():
+    """fp8 static scales are derived from the weights: after an optimizer step they are stale and the fp8 path must say so."""
+    m = M()
+    from image_restoration_amd import restormer
+    from image_restoration_amd.trainer import FlatTrainer
+    torch.manual_seed(1)
+    net = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
+    x = seeded_input((2, 48, 32, 64), 32).to(DEV).to(torch.bfloat16)
+    restormer.fp8_calibrate(net, [x])
+    restormer.fp8_projections(net, "all")
+    with torch.no_grad():
+        net(x)
+    tr = FlatTrainer(net, lr=1e-2)
+    try:
+        _train_steps(tr, net, x, 1)
+        with torch.no_grad(), pytest.raises(RuntimeError, match="fp8_calibrate"):
+            net(x)
+        restormer.fp8_calibrate(net, [x])
+        with torch.no_grad():
+            net(x)
+    finally:
+        tr.close()
+        restormer.fp8_projections(net, None)
+
+
+def test_packed_weights_inside_a_training_run_borrows_the_trainers_cache():
+    """per-epoch validation through inference.PackedWeights on a model a FlatTrainer owns must not cut the
+    parameters loose from the trainer's flat buffer: training continues to move the weights afterwards, and the validation
+    sees the current ones."""
+    m = M()
+    from image_restoration_amd import inference, ops
+    from image_restoration_amd.configs import RESTORMER_TINY
+    from image_restoration_amd.trainer import FlatTrainer
+    torch.manual_seed(2)
+    net = m.Restormer(**RESTORMER_TINY).to(DEV)
+    tr = FlatTrainer(net, lr=2e-2)
+    x = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16)
+    try:
+        _train_steps(tr, net, x, 1)
+        owner = ops.pw_cache_owner()
+        with inference.PackedWeights(net) as pk:
+            assert pk._borrowed and ops.pw_cache_owner() is owner
+            with torch.no_grad():
+                y1 = net(x).float()
+        assert ops.pw_cache_owner() is owner, "closing the borrowed PackedWeights switched the trainer's cache off"
+        p0 = next(net.parameters())
+        assert p0.data_ptr() >= tr.flat_p.data_ptr() and p0.data_ptr() < tr.flat_p.data_ptr() + tr.flat_p.numel() * 4
+        before = tr.flat_p.clone()
+        _train_steps(tr, net, x, 2)
+        assert not torch.equal(before, tr.flat_p)
+        with torch.no_grad():
+            y2 = net(x).float()
+        assert not torch.equal(y1, y2), "the model stopped following the optimizer"
+        ref = m.Restormer(**RESTORMER_TINY)
+        ref.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()})
+        tr.close()
+        with torch.no_grad():
+            want = ref.to(DEV)(x).float()
+        assert torch.equal(y2, want), float((y2 - want).abs().max())
+        # an un-owned model: PackedWeights takes its own flat copy and hands the parameters back on close
+        solo = m.Restormer(**RESTORMER_TINY).to(DEV).eval()
+        ptrs = [p.data_ptr() for p in solo.parameters()]
+        with torch.no_grad():
+            a = solo(x).float()
+            with inference.PackedWeights(solo):
+                b = solo(x).float()
+                c = solo(x).float()
+            d = solo(x).float()
+        assert [p.data_ptr() for p in solo.parameters()] == ptrs
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+        assert ops.pw_cache_owner() is None
+    finally:
+        tr.close()
+
+
+def test_later_cache_owner_survives_an_earlier_trainers_finaliser():
+    """`tr = FlatTrainer(net2)` rebinding - the old trainer's close() must not disable the new owner's cache."""
+    m = M()
+    from image_restoration_amd import ops
+    from image_restoration_amd.trainer import FlatTrainer
+    a = FlatTrainer(m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV))
+    b = FlatTrainer(m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV))
+    tok = ops.pw_cache_owner()
+    assert tok is b._cache_token
+    a.close()
+    assert ops.pw_cache_owner() is tok
+    b.close()
+    assert ops.pw_cache_owner() is None
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("cin,cout,hw", [(3, 16, (8, 8)), (16, 8, (8, 8)), (8, 16, (24, 40)), (16, 3, (7, 9)), (4, 8, (4, 512)),
+                                         (8, 4, (16, 1024))])
+def test_glue_conv3x3_on_planes_outside_the_streaming_set(dtype, tol, cin, cout, hw):
+    """Dense 3x3 glue convolution (+ bias + residual) on rows that are not a power of two in 16..256 (8 x 8 latent planes, ragged
+    planes, 512 / 1024-pixel rows): the general im2col / col2im forms, forward and all gradients vs F.conv2d in fp64 on the
+    host.  Round 2 sent these through MIOpen."""
+    import torch.nn as nn
+    import image_restoration_amd.restormer as rs
+    H, W = hw
+    conv = nn.Conv2d(cin, cout, 3, padding=1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(seeded_input(tuple(conv.weight.shape), 61) * 0.3)
+        conv.bias.copy_(seeded_input((cout,), 62) * 0.1)
+    x = seeded_input((2, cin, H, W), 63)
+    res = seeded_input((2, cout, H, W), 64)
+    cot = seeded_input((2, cout, H, W), 65)
+    cg = conv.to(DEV)
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    rg = res.to(DEV).to(dtype).requires_grad_(True)
+    y = rs._conv2d(xg, cg, rg)
+    y.backward(cot.to(DEV).to(dtype))
+    xr = xg.detach().double().cpu().requires_grad_(True)
+    rr = rg.detach().double().cpu().requires_grad_(True)
+    wr = conv.weight.detach().double().cpu().requires_grad_(True)
+    br = conv.bias.detach().double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1) + rr
+    yr.backward(cot.to(dtype).double())
+    assert rel(y, yr) < tol
+    assert rel(xg.grad, xr.grad) < 2 * tol and rel(rg.grad, rr.grad) < tol
+    assert rel(cg.weight.grad, wr.grad) < 4 * tol and rel(cg.bias.grad, br.grad) < 4 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 3, 5), (1, 4, 8, 12), (2, 16, 4, 516)])
+def test_pixel_shuffle_and_concat_on_ragged_rows(dtype, shape):
+    """PixelShuffle / PixelUnshuffle / the in-place concatenation on rows that are not a multiple of the vector width: exact."""
+    import image_restoration_amd.restormer as rs
+    x = seeded_input(shape, 71).to(dtype)
+    xg = x.to(DEV).requires_grad_(True)
+    up = rs._shuffle(xg, False)
+    assert torch.equal(up.cpu(), F.pixel_shuffle(x, 2))
+    assert torch.equal(rs._shuffle(up.detach(), True).cpu(), x)
+    cot = seeded_input(tuple(up.shape), 72).to(dtype)
+    up.backward(cot.to(DEV))
+    assert torch.equal(xg.grad.cpu(), F.pixel_unshuffle(cot, 2))
+    skip = seeded_input((shape[0], 3, 2 * shape[2], 2 * shape[3]), 73).to(dtype).to(DEV)
+    cat = rs._UpCatFn.apply(xg.detach(), skip)
+    assert torch.equal(cat.cpu(), torch.cat([F.pixel_shuffle(x, 2), skip.cpu()], 1))
+
+
+def test_fft_attention_refuses_patch_sizes_without_a_native_kernel():
+    import image_restoration_amd.moce_ir as mo
+    fa = mo.FFTAttention(8, patch_size=5, kernel_size=3).to(DEV)
+    with pytest.raises(NotImplementedError, match="patch_size 5"):
+        fa(torch.zeros(1, 8, 10, 10, device=DEV))
+
+
+def test_restormer_runs_natively_on_a_64px_input_and_a_512px_tile():
+    """A 64^2 input reaches 8 x 8 latent planes, a 512-pixel tile 512-wide rows: both used to leave the native path for the glue
+    convolutions.  Whole tiny network vs the oracle (fp32 activations)."""
+    m = M()
+    from image_restoration_amd.configs import RESTORMER_TINY
+    sd = R.make_restormer_state(RESTORMER_TINY, seed=9)
+    net = m.Restormer(**RESTORMER_TINY)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    for hw in ((64, 64), (32, 512)):
+        x = torch.rand((1, 3) + hw, generator=torch.Generator().manual_seed(hw[1]))
+        with torch.no_grad():
+            y = net(x.to(DEV))
+            ref = R.restormer_forward(x.double(), {k: v.double() for k, v in sd.items()}, RESTORMER_TINY)
+        assert rel(y, ref) < 1e-4, (hw, rel(y, ref))
+
+
+# ------------------------------------------------------------------------------------------------ torch.library custom ops
+def _block_inputs(c, heads, bias, dtype, shape, seed):
+    m = M()
+    sd = R.make_block_state(c, heads, 2.66, bias, "WithBias", seed=seed)
+    blk = m.TransformerBlock(c, heads, 2.66, bias, "WithBias")
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    x = seeded_input(shape, seed + 1).to(DEV).to(dtype)
+    return blk, x
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_custom_ops_pass_opcheck(dtype):
+    """torch.library.opcheck on real GPU inputs: schema (no undeclared aliasing / mutation), autograd registration, and the fake
+    implementations against the real ops' output metadata - for all four forward ops and the block backward op."""
+    from torch.library import opcheck
+    from image_restoration_amd import torch_ops  # noqa: F401
+    blk, x = _block_inputs(48, 1, False, dtype, (2, 48, 16, 64), 81)
+    params = blk.norm1._params() + blk.attn._params() + blk.norm2._params() + blk.ffn._params()
+    tests = ("test_schema", "test_autograd_registration", "test_faketensor")
+    xg = x.clone().requires_grad_(True)
+    opcheck(torch.ops.mi_restore.transformer_block_fwd.default, (xg, 1) + tuple(params) + (True,), test_utils=tests)
+    opcheck(torch.ops.mi_restore.transformer_block_fwd.default, (x, 1) + tuple(params) + (False,), test_utils=tests)
+    opcheck(torch.ops.mi_restore.layernorm_fwd.default, (xg,) + tuple(blk.norm1._params()) + (True,), test_utils=tests)
+    opcheck(torch.ops.mi_restore.mdta_fwd.default, (xg, 1) + tuple(blk.attn._params()) + (True,), test_utils=tests)
+    opcheck(torch.ops.mi_restore.gdfn_fwd.default, (xg,) + tuple(blk.ffn._params()) + (True,), test_utils=tests)
+    outs = torch.ops.mi_restore.transformer_block_fwd(x, 1, *params, True)
+    opcheck(torch.ops.mi_restore.transformer_block_bwd.default,
+            (torch.ones_like(x), x, 1) + tuple(params) + (list(outs[1:]), False), test_utils=("test_schema", "test_faketensor"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_custom_op_route_equals_autograd_function_route(monkeypatch, dtype, bias):
+    """The modules' default door (mi_restore:: custom ops) and the bare autograd.Function nodes (MI_TORCH_OPS=0) run the same
+    kernels: outputs and every gradient bit-identical, for the block and for the three stand-alone modules."""
+    def run(mod_fn, x0):
+        mod, args = mod_fn()
+        xs = [a.clone().requires_grad_(True) for a in args]
+        y = mod(*xs)
+        y.backward(torch.ones_like(y))
+        return [y.detach()] + [a.grad for a in xs] + [p.grad for _, p in sorted(mod.named_parameters())]
+
+    m = M()
+    x = seeded_input((2, 48, 16, 64), 91).to(DEV).to(dtype)
+
+    def mk(cls, *a):
+        def f():
+            torch.manual_seed(5)
+            return cls(*a).to(DEV), [x]
+        return f
+    for make in (mk(m.TransformerBlock, 48, 2, 2.66, bias, "WithBias"), mk(m.LayerNorm, 48, "BiasFree"),
+                 mk(m.Attention, 48, 2, bias), mk(m.FeedForward, 48, 2.66, bias)):
+        monkeypatch.delenv("MI_TORCH_OPS", raising=False)
+        a = run(make, x)
+        monkeypatch.setenv("MI_TORCH_OPS", "0")
+        b = run(make, x)
+        monkeypatch.delenv("MI_TORCH_OPS")
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)

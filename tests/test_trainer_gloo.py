@@ -191,6 +191,84 @@ def test_unrouted_expert_zero_bucket_and_accumulation():
     assert ret["refused"]
 
 
+class TinyContainers(nn.Module):
+    """the shapes the trainer's 'did not run this step' shortcut was unsound for - a ModuleList as the LAST
+    child (its forward hook can never fire: MoCE-IR's enc / dec), a module whose weights are used functionally (its forward is
+    never called: Restormer's reduce_chan / output / up2_1), and a bare-parameter container."""
+
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Conv2d(3, 4, 1)
+        self.mid = nn.Conv2d(4, 4, 1)                                  # used functionally (weights read, forward never called)
+        self.groups = nn.ModuleList([nn.ModuleList([nn.Conv2d(4, 4, 1), nn.Conv2d(4, 4, 1)]), nn.Conv2d(4, 3, 1)])
+
+    def forward(self, x):
+        from image_restoration_amd.restormer import _fire_forward_hooks
+        h = self.embed(x)
+        y = torch.nn.functional.conv2d(h, self.mid.weight, self.mid.bias)
+        _fire_forward_hooks(self.mid, (h,), y)                         # what the package's functional uses do
+        for blk in self.groups[0]:
+            y = blk(y)
+        return self.groups[1](y)
+
+
+def _worker_containers(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_restoration_amd.trainer import FlatTrainer
+        torch.manual_seed(0)
+        model = TinyContainers()
+        tr = FlatTrainer(model, lr=1e-2, overlap=True, host_update=_host_adamw)
+        names = [n for n, *_ in tr.stages]
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(4, 3, 4, 4, generator=g)
+        y = torch.randn(4, 3, 4, 4, generator=g)
+        launched = []
+        orig = tr._launch_reduce
+
+        def spy(idx):
+            # at the moment a bucket is handed to the collective, every gradient of its stage must already be in it
+            _, child, lo, hi = tr.stages[idx]
+            tr._fold_autograd_grads(child)
+            launched.append((names[idx], float(tr.flat_g[lo:hi].abs().sum())))
+            orig(idx)
+        tr._launch_reduce = spy
+        for _ in range(2):
+            tr.zero_grad()
+            (model(x[rank * 2:rank * 2 + 2]) - y[rank * 2:rank * 2 + 2]).abs().mean().backward()
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        if rank == 0:
+            ret["params"] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            ret["names"] = names
+            ret["launched"] = launched
+    finally:
+        dist.destroy_process_group()
+
+
+def test_containers_and_functional_modules_are_not_reduced_early():
+    torch.manual_seed(0)
+    ref = TinyContainers()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 4, 4, generator=g)
+    y = torch.randn(4, 3, 4, 4, generator=g)
+    for _ in range(2):
+        opt.zero_grad()
+        (ref(x) - y).abs().mean().backward()
+        opt.step()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_containers, args=(2, _free_port(), ret), nprocs=2, join=True)
+    # the ModuleLists were expanded into their elements: every stage is a module with a forward of its own
+    assert ret["names"] == ["embed", "mid", "groups.0.0", "groups.0.1", "groups.1"]
+    # no bucket went out empty (a stage reduced before its gradients were written would show a zero sum here)
+    assert all(s > 0 for _, s in ret["launched"]), ret["launched"]
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(ret["params"][k], v, rtol=1e-5, atol=1e-6), k
+
+
 def test_cosine_warmup_schedule_closed_form():
     """LinearWarmupCosineAnnealingLR(warmup 15, max 150) closed form (MoCE-IR-main/src/utils/schedulers.py:332-346):
     hand-computed points."""
