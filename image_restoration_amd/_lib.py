@@ -188,6 +188,11 @@ SIGNATURES = {
     "mi_gdfn_fused_pack": (C.c_int, [C.POINTER(GdfnFusedShape), fp, fp, C.POINTER(GdfnParams), vp, vp]),
     "mi_gdfn_fused_fwd": (C.c_int, [C.POINTER(GdfnFusedShape), vp, vp, vp, fp, fp, vp]),
     "mi_gdfn_fused_fwd_f8": (C.c_int, [C.POINTER(GdfnFusedShape), vp, C.POINTER(F8Scales), vp, vp, vp]),
+    "mi_mdta_fused_ok": (C.c_int, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fused_pack_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fused_pack": (C.c_int, [C.POINTER(MdtaShape), fp, fp, C.POINTER(MdtaParams), vp, vp]),
+    "mi_mdta_fused_workspace": (C.c_size_t, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fused_fwd": (C.c_int, [C.POINTER(MdtaShape), C.POINTER(MdtaParams), vp, C.c_int, vp, vp, vp, fp, fp, vp, vp]),
     "mi_adamw_step": (C.c_int, [fp, fp, fp, fp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, fp, vp]),
     "mi_rows_gather": (C.c_int, [vp, vp, vp, C.c_int, c_i64, C.c_int, vp]),

@@ -588,6 +588,44 @@ def gdfn_fused_fwd(y: Tensor, pack: Tensor, hidden: int, with_bias: bool, want_s
     return out, mean, rstd
 
 
+def mdta_fused_ok(x: Tensor, heads: int, ks: int = 3) -> bool:
+    """True when the one-launch LN -> qkv -> dw3x3 -> q k^T pass (csrc/fused_mdta.hip) covers this activation."""
+    if x.dtype != torch.bfloat16 or ks != 3 or not x.is_cuda:
+        return False
+    return bool(L.lib().mi_mdta_fused_ok(C.byref(_mdta_shape(x, heads, ks))))
+
+
+def mdta_fused_pack(x_like: Tensor, heads: int, ln_w: Tensor, ln_b: Optional[Tensor], params: "MdtaParamsT") -> Tensor:
+    """LayerNorm affine + qkv / depthwise parameters -> the fused MDTA kernel's packed weight images."""
+    _gpu(ln_w, ln_b, *params)
+    for t in (ln_w, ln_b) + tuple(params):
+        _f32(t, "fused MDTA parameter")
+    s = _mdta_shape(x_like, heads, params[3].shape[-1])
+    lib = L.lib()
+    pack = _blob(lib.mi_mdta_fused_pack_bytes(C.byref(s)), ln_w.device)
+    L.check(lib.mi_mdta_fused_pack(C.byref(s), _p(ln_w), _p(ln_b), C.byref(_mdta_params(params)), _p(pack), _stream()),
+            "mdta_fused_pack")
+    return pack
+
+
+def mdta_fused_fwd(x: Tensor, pack: Tensor, params: "MdtaParamsT", heads: int, with_bias: bool, residual: Optional[Tensor],
+                   want_stats: bool = False):
+    """out = residual + MDTA(LN(x)) with the whole producer chain of q k^T in one launch (nothing saved: the no_grad path).
+    -> (out, mean, rstd)."""
+    _gpu(x, pack, residual, *params)
+    s = _mdta_shape(x, heads, params[3].shape[-1])
+    lib = L.lib()
+    out = torch.empty_like(x)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty((x.shape[0], x.shape[2] * x.shape[3]), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    ws = _ws(lib.mi_mdta_fused_workspace(C.byref(s)), x.device)
+    L.check(lib.mi_mdta_fused_fwd(C.byref(s), C.byref(_mdta_params(params)), _p(pack), int(with_bias), _p(x), _p(residual),
+                                  _p(out), _p(mean), _p(rstd), _p(ws), _stream()), "mdta_fused_fwd")
+    return out, mean, rstd
+
+
 # ----------------------------------------------------------------------------- router GAP
 def rows_gather(x: Tensor, idx: Tensor) -> Tensor:
     """out[i] = x[idx[i]] over whole [C,H,W] rows (SparseDispatcher.dispatch)."""

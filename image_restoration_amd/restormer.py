@@ -254,6 +254,17 @@ def _fused_gdfn_pack(holder, like: Tensor, ln_params, ffn_params) -> Tensor:
     return cache[1]
 
 
+def _fused_mdta_pack(holder, like: Tensor, heads: int, ln_params, att_params) -> Tensor:
+    """Packed weights of the one-launch LN -> qkv -> dw3x3 -> q k^T kernel (csrc/fused_mdta.hip), cached like _fused_gdfn_pack."""
+    ps = tuple(ln_params) + tuple(att_params[1:5])
+    key = (tuple((p.data_ptr(), p._version) if p is not None else None for p in ps) + (ops.weights_epoch(),))
+    cache = getattr(holder, "_fm_pack", None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.mdta_fused_pack(like, heads, ln_params[0], ln_params[1], tuple(att_params)))
+        holder._fm_pack = cache
+    return cache[1]
+
+
 # ---- fp8 (e4m3) MFMA operands in the 1x1 projections: the tiled-inference configuration (BASELINE configs[4]) -------------------
 # Activations stay bf16 in HBM; a projection's input and weight are divided by a power-of-two scale and rounded to e4m3 in
 # registers on their way into v_mfma_f32_16x16x32_fp8_fp8 (csrc/pw_gemm.hip, PwwOp).  Weight scales come from the weights
@@ -361,7 +372,10 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
     f8_a = block._f8["attn"] if mode and ops.mdta_fwd_f8_ok(x, heads, ks_a, bool(ln_a)) else None
     if mode:
         F8_COUNTS["f8" if f8_a else "bf16"] += 2
-    if ln_a:
+    if f8_a is None and ops.mdta_fused_ok(x, heads, ks_a) and not ops.env("MI_NO_FUSED_INFER"):
+        # pass A in one launch: LN -> qkv -> dw3x3 -> q k^T partials; only v is written (q, k, qkv0 never reach HBM)
+        y = ops.mdta_fused_fwd(x, _fused_mdta_pack(block, x, heads, n1, att), att, heads, wb, x)[0]
+    elif ln_a:
         y = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], False), f8=f8_a)
         y = y if f8_a else y[0]
     else:

@@ -54,13 +54,22 @@ def _unpack(saved: Sequence[Tensor]) -> List[Optional[Tensor]]:
     return [t if t.numel() else None for t in saved]
 
 
+# Hand-off of the trainer's gradient buffers around the dispatcher (the ops' tensor arguments reach the op bodies as plain
+# tensors: attributes of the caller's Parameter objects do not travel).  "next": set by the module-level wrappers right before a
+# forward op call, consumed by that call's setup_context; "bwd": set by the autograd backward around the backward op call.
+# Backward runs on autograd's thread for the device, forward on the caller's: the two keys never race on one device.
+_MAIN_GRADS: dict = {}
+
+
 def _grads_for(params: Sequence[Optional[Tensor]], accumulate: bool):
     """Gradient buffers of a backward op: the parameters' main_grad buffers (accumulate) or fresh tensors."""
     if accumulate:
-        mg = [None if p is None else getattr(p, "main_grad", None) for p in params]
+        mg = _MAIN_GRADS.get("bwd")
+        if mg is None:
+            mg = [None if p is None else getattr(p, "main_grad", None) for p in params]
         if any(p is not None and g is None for p, g in zip(params, mg)):
             raise RuntimeError("accumulate=True needs a main_grad buffer on every parameter (FlatTrainer sets them)")
-        return mg
+        return list(mg)
     return [None if p is None else torch.empty_like(p) for p in params]
 
 
@@ -95,21 +104,26 @@ def _register(name: str, fwd_schema: str, bwd_schema: str, fwd_impl, fwd_fake, b
         lead, params = inputs[:n_lead], inputs[n_lead:n_lead + n_params]
         ctx.scalars = [v for v in lead if not isinstance(v, Tensor)]
         ctx.lead_is_tensor = [isinstance(v, Tensor) for v in lead]
-        ctx.present = [p is not None for p in params]
-        ctx.n_saved = len(output) - 1
-        # parameters keep their Python identity here (main_grad lives on the Parameter object, not in the tensor)
-        ctx.params = params
-        ctx.save_for_backward(*[v for v in lead if isinstance(v, Tensor)], *output[1:])
+        ctx.n_params_present = [p is not None for p in params]
+        # The tensors autograd hands to setup_context are not the caller's Parameter objects, so the trainer's per-parameter
+        # ``main_grad`` buffers (attributes of those objects) are picked up from the wrapper's hand-off (_MAIN_GRADS) instead.
+        ctx.mg = _MAIN_GRADS.pop("next", None)
+        ctx.save_for_backward(*[v for v in lead if isinstance(v, Tensor)], *[p for p in params if p is not None], *output[1:])
 
     def backward(ctx, grads):
         dout = grads[0]
         tens = list(ctx.saved_tensors)
         n_lt = sum(ctx.lead_is_tensor)
-        lead_t, saved = tens[:n_lt], tens[n_lt:]
-        params = ctx.params
-        accumulate = all(getattr(p, "main_grad", None) is not None for p in params if p is not None) and any(
-            p is not None for p in params)
-        res = bwd_op(dout.contiguous(), *lead_t, *ctx.scalars, *params, saved, accumulate)
+        n_pp = sum(ctx.n_params_present)
+        lead_t, ptens, saved = tens[:n_lt], tens[n_lt:n_lt + n_pp], tens[n_lt + n_pp:]
+        it = iter(ptens)
+        params = [next(it) if pr else None for pr in ctx.n_params_present]
+        accumulate = ctx.mg is not None
+        _MAIN_GRADS["bwd"] = ctx.mg
+        try:
+            res = bwd_op(dout.contiguous(), *lead_t, *ctx.scalars, *params, saved, accumulate)
+        finally:
+            _MAIN_GRADS.pop("bwd", None)
         d_lead_t = list(res[:n_lt])
         d_par = res[n_lt:]
         out = []
@@ -240,7 +254,8 @@ gdfn_fwd, gdfn_bwd = _register(
     _gdfn_fwd, _gdfn_fwd_fake, _gdfn_bwd, _gdfn_bwd_fake, n_params=6, n_lead=1, n_tail=1)
 
 # ------------------------------------------------------------------------------------------------ TransformerBlock
-_BK_P = (("n1_w", "n1_b") + _AT_P + ("n2_w", "n2_b") + _FF_P)
+_BK_P = (("n1_w", "n1_b", "temperature", "qkv_w", "qkv_b", "qkv_dw_w", "qkv_dw_b", "proj_w", "proj_b", "n2_w", "n2_b")
+         + ("in_w", "in_b", "ffn_dw_w", "ffn_dw_b", "out_w", "out_b"))
 _BK_O = ((False, True) + _AT_O + (False, True) + _FF_O)
 
 
@@ -292,7 +307,13 @@ OPS = {"layernorm": (layernorm_fwd, layernorm_bwd), "mdta": (mdta_fwd, mdta_bwd)
 
 
 def _need(x: Tensor, params) -> bool:
-    return torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+    _MAIN_GRADS.pop("next", None)
+    if need:
+        mg = [None if p is None else getattr(p, "main_grad", None) for p in params]
+        if any(p is not None for p in params) and all(g is not None for p, g in zip(params, mg) if p is not None):
+            _MAIN_GRADS["next"] = mg
+    return need
 
 
 def layernorm(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:

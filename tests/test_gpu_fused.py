@@ -370,3 +370,72 @@ def test_full_size_batch_is_consistent_with_a_small_one(c, heads, hw):
     assert torch.equal(yb[0], yb[15]) and torch.equal(yb[16], yb[31]) and torch.equal(dxb[0], dxb[15])   # copies inside one batch: exact
     for k in gs:
         assert rel(gb[k], 16.0 * gs[k]) < 2e-2, (k, rel(gb[k], 16.0 * gs[k]))
+
+
+# ------------------------------------------------------------------------------------------------ fused MDTA, pass A (csrc/fused_mdta.hip)
+def _oracle_attn_half(x, sd, heads, kind):
+    """x + attn(norm1(x)) in fp64 (Restormer.py:147)."""
+    d = {k: v.double() for k, v in sd.items()}
+    xn = R.layernorm_nchw(x.double(), d["norm1.body.weight"], d.get("norm1.body.bias"), kind)
+    return x.double() + R.mdta(xn, d["attn.temperature"], d["attn.qkv.weight"], d["attn.qkv_dwconv.weight"],
+                               d["attn.project_out.weight"], heads, d.get("attn.qkv.bias"), d.get("attn.qkv_dwconv.bias"),
+                               d.get("attn.project_out.bias"))
+
+
+FM_CASES = [
+    # C, heads, bias, LN kind, shape
+    (48, 1, False, "WithBias", (2, 48, 16, 64)),
+    (48, 1, True, "BiasFree", (1, 48, 8, 128)),
+    (96, 2, False, "WithBias", (2, 96, 24, 64)),
+    (96, 1, False, "WithBias", (2, 96, 16, 64)),
+    (96, 1, True, "WithBias", (3, 96, 40, 128)),       # 3 images x 20 tiles over 32 splits: uneven tile ranges, workgroups with one tile
+    (96, 2, True, "BiasFree", (1, 96, 64, 64)),
+]
+
+
+@pytest.mark.parametrize("c,heads,bias,kind,shape", FM_CASES)
+def test_mdta_fused_pass_a_vs_oracle_and_chain(c, heads, bias, kind, shape):
+    """x + attn(norm1(x)) with LN -> qkv -> dw3x3 -> q k^T in ONE launch (q, k, qkv0 never written) against the fp64 oracle and
+    against the unfused kernel chain it replaces; the LayerNorm statistics it can emit against the LayerNorm kernel's."""
+    m = M()
+    from image_restoration_amd import ops
+    sd = R.make_block_state(c, heads, 2.66, bias, kind, seed=130 + c + heads)
+    x = seeded_input(shape, 1300 + c).to(DEV).to(torch.bfloat16)
+    ref = _oracle_attn_half(x.float().cpu(), sd, heads, kind)
+    ln = (sd["norm1.body.weight"].to(DEV), sd["norm1.body.bias"].to(DEV) if "norm1.body.bias" in sd else None)
+    keys = ["attn.temperature", "attn.qkv.weight", "attn.qkv.bias", "attn.qkv_dwconv.weight", "attn.qkv_dwconv.bias",
+            "attn.project_out.weight", "attn.project_out.bias"]
+    att = tuple(sd[k].to(DEV).float().contiguous() if k in sd else None for k in keys)
+    assert ops.mdta_fused_ok(x, heads, 3)
+    pack = ops.mdta_fused_pack(x, heads, ln[0], ln[1], att)
+    y, mean, rstd = ops.mdta_fused_fwd(x, pack, att, heads, kind == "WithBias", x, want_stats=True)
+    xn, mean_r, rstd_r = ops.ln_fwd(x, ln[0], ln[1], kind == "WithBias", want_stats=True)
+    chain, _ = ops.mdta_fwd(xn, x, att, heads, False)
+    e_or, e_ch = rel(y, ref), rel(chain, ref)
+    assert e_or < 2e-2, (e_or, e_ch)
+    assert e_or < 1.5 * e_ch + 4e-3, (e_or, e_ch)            # no further from the oracle than the chain (fewer bf16 intermediates)
+    assert rel(mean, mean_r) < 1e-5 and rel(rstd, rstd_r) < 1e-4
+    y2, _, _ = ops.mdta_fused_fwd(x, pack, att, heads, kind == "WithBias", x)
+    assert torch.equal(y, y2)                                # fixed-order partial sums: bit-reproducible
+
+
+def test_block_infer_takes_the_fused_mdta_kernel():
+    """TransformerBlock.forward under no_grad: both halves are one-launch kernels where the shapes allow; output vs the oracle."""
+    m = M()
+    c, heads, shape = 96, 1, (2, 96, 32, 64)
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=141)
+    blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+    blk.load_state_dict(sd)
+    x = seeded_input(shape, 1410).to(DEV).to(torch.bfloat16)
+    ref = R.transformer_block(x.float().cpu().double(), {k: v.double() for k, v in sd.items()}, heads, "WithBias")
+    with torch.no_grad():
+        y = blk(x)
+    assert getattr(blk, "_fm_pack", None) is not None and getattr(blk, "_fg_pack", None) is not None
+    assert rel(y, ref) < 2e-2, rel(y, ref)
+    with torch.no_grad():                                   # a weight written in place: the pack follows
+        blk.attn.qkv.weight.mul_(0.5)
+        y2 = blk(x)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["attn.qkv.weight"] = sd2["attn.qkv.weight"] * 0.5
+    ref2 = R.transformer_block(x.float().cpu().double(), {k: v.double() for k, v in sd2.items()}, heads, "WithBias")
+    assert rel(y2, ref2) < 2e-2
