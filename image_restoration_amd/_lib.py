@@ -94,6 +94,12 @@ class LnTail(C.Structure):
     _fields_ = [("w", fp), ("b", fp), ("mean", fp), ("rstd", fp), ("dres", vp), ("dw", fp), ("db", fp)]
 
 
+class GroupedProblem(C.Structure):
+    _fields_ = [("x", vp), ("x_rs", c_i64), ("w", fp), ("w_sm", c_i64), ("w_sk", c_i64), ("bias", fp), ("r", vp), ("r_rs", c_i64),
+                ("y", vp), ("y_rs", c_i64), ("m", C.c_int), ("k", C.c_int), ("expert", C.c_int), ("x_local", C.c_int),
+                ("y_local", C.c_int), ("r_local", C.c_int)]
+
+
 class GdfnGrads(C.Structure):
     _fields_ = [("in_w", fp), ("in_b", fp), ("dw_w", fp), ("dw_b", fp), ("out_w", fp), ("out_b", fp),
                 ("accumulate", C.c_int)]
@@ -203,6 +209,7 @@ SIGNATURES = {
     "mi_glue3x3_ok": (C.c_int, [C.c_int, C.c_int]),
     "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_grouped_pw_gemm": (C.c_int, [C.POINTER(GroupedProblem), C.c_int, vp, vp, C.c_int, c_i64, C.c_int, vp]),
     "mi_moe_route_fwd": (C.c_int, [fp, fp, fp, fp, fp, fp, fp, fp, vp, fp, fp, vp, vp, vp, fp, vp, vp, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, vp]),
     "mi_moe_route_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, fp, vp, fp, fp, vp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int,

@@ -221,22 +221,92 @@ class _FFTCoreFn(torch.autograd.Function):
         return dq, dkv, (None if acc else dw), (None if acc else db), None
 
 
-class _ExpertsOutFn(torch.autograd.Function):
-    """Last step of every expert at once (:556-558): out[rows of e] = proj[2]_e(t_e) + x[rows of e], written by the E
-    pointwise GEMMs into ONE row-stitched buffer (the reference concatenates the experts' outputs afterwards, :116)."""
+def _w2(w: Tensor) -> Tensor:
+    return w.reshape(w.shape[0], -1)
+
+
+class _ExpertsInFn(torch.autograd.Function):
+    """First step of every expert at once (:552-555): a_e = proj[0]_e(x[rows of e]), g_e = proj[1]_e(shared[rows of e]) for all
+    E experts in ONE grouped launch (csrc/grouped.hip) that reads the segment sizes / starts from the router's device tables.
+    Backward: the two input gradients of all experts in one grouped launch (each expert writes its own row segment of the
+    stitched gradient buffers); the weight gradients are per-expert Grams."""
 
     @staticmethod
-    def forward(ctx, xrows, counts, *tw):
+    def forward(ctx, xrows, srows, counts, dev_counts, dev_offsets, *ws):
+        E = len(counts)
+        w0, w1 = ws[:E], ws[E:]
+        R, Cc, H, W = xrows.shape
+        N = H * W
+        outs_a = [torch.empty((n, w0[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
+        outs_g = [torch.empty((n, w1[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
+        probs = []
+        for e, n in enumerate(counts):
+            if n:
+                probs.append(dict(x=xrows, w=_w2(w0[e]), y=outs_a[e], m=w0[e].shape[0], k=Cc, expert=e, y_local=True))
+                probs.append(dict(x=srows, w=_w2(w1[e]), y=outs_g[e], m=w1[e].shape[0], k=Cc, expert=e, y_local=True))
+        if probs:
+            ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, N, xrows.dtype)
+        ctx.counts = counts
+        ctx.save_for_backward(xrows, srows, dev_counts, dev_offsets, *ws)
+        ctx.mg = [getattr(w, "main_grad", None) for w in ws]
+        return tuple(outs_a) + tuple(outs_g)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        xrows, srows, dev_counts, dev_offsets, *ws = ctx.saved_tensors
+        counts = ctx.counts
+        E = len(counts)
+        w0, w1 = ws[:E], ws[E:]
+        R, Cc, H, W = xrows.shape
+        da, dg = [d.contiguous() if d is not None else None for d in douts[:E]], [d.contiguous() if d is not None else None for d in douts[E:]]
+        dx, ds = torch.empty_like(xrows), torch.empty_like(srows)
+        probs = []
+        for e, n in enumerate(counts):
+            if not n:
+                continue
+            if da[e] is None:
+                da[e] = torch.zeros((n, w0[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device)
+            if dg[e] is None:
+                dg[e] = torch.zeros((n, w1[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device)
+            probs.append(dict(x=da[e], w=_w2(w0[e]), transposed=True, y=dx, m=Cc, k=w0[e].shape[0], expert=e, x_local=True))
+            probs.append(dict(x=dg[e], w=_w2(w1[e]), transposed=True, y=ds, m=Cc, k=w1[e].shape[0], expert=e, x_local=True))
+        if probs:
+            ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, xrows.dtype)
+        dws = []
+        o = 0
+        for which, (d_list, src) in enumerate(((da, xrows), (dg, srows))):
+            o = 0
+            for e, n in enumerate(counts):
+                w = ws[which * E + e]
+                if not n:
+                    dws.append(None)
+                    continue
+                g = ops.gram(d_list[e], src[o:o + n], 1, True)[0].reshape(w.shape)
+                if ctx.mg[which * E + e] is not None:
+                    ctx.mg[which * E + e].add_(g)
+                    g = None
+                dws.append(g)
+                o += n
+        return (dx, ds, None, None, None) + tuple(dws)
+
+
+class _ExpertsOutFn(torch.autograd.Function):
+    """Last step of every expert at once (:556-558): out[rows of e] = proj[2]_e(t_e) + x[rows of e], written by ONE grouped
+    launch into ONE row-stitched buffer (the reference concatenates the experts' outputs afterwards, :116); the input
+    gradients dt_e = proj[2]_e^T dout[rows of e] of all experts are one grouped launch too."""
+
+    @staticmethod
+    def forward(ctx, xrows, counts, dev_counts, dev_offsets, *tw):
         E = len(counts)
         ts, ws = tw[:E], tw[E:]
         out = torch.empty_like(xrows)
-        o = 0
-        for e, n in enumerate(counts):
-            if n:
-                ops.conv1x1(ts[e], ws[e], None, xrows[o:o + n], out=out[o:o + n])
-                o += n
+        R, Cc, H, W = xrows.shape
+        probs = [dict(x=ts[e], w=_w2(ws[e]), r=xrows, y=out, m=Cc, k=ws[e].shape[1], expert=e, x_local=True)
+                 for e, n in enumerate(counts) if n]
+        if probs:
+            ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, xrows.dtype)
         ctx.counts = counts
-        ctx.save_for_backward(*[t for t in ts if t is not None], *ws)
+        ctx.save_for_backward(dev_counts, dev_offsets, *[t for t in ts if t is not None], *ws)
         ctx.present = [t is not None for t in ts]
         ctx.mg = [getattr(w, "main_grad", None) for w in ws]
         return out
@@ -245,26 +315,30 @@ class _ExpertsOutFn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = dout.contiguous()
         E = len(ctx.counts)
-        saved = list(ctx.saved_tensors)
+        dev_counts, dev_offsets, *saved = ctx.saved_tensors
         nt = sum(ctx.present)
         it = iter(saved[:nt])
         ts = [next(it) if pr else None for pr in ctx.present]
         ws = saved[nt:]
-        dts, dws = [], []
+        R, Cc, H, W = dout.shape
+        dts = [torch.empty_like(t) if t is not None else None for t in ts]
+        probs = [dict(x=dout, w=_w2(ws[e]), transposed=True, y=dts[e], m=ws[e].shape[1], k=Cc, expert=e, y_local=True)
+                 for e, n in enumerate(ctx.counts) if n]
+        if probs:
+            ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, dout.dtype)
+        dws = []
         o = 0
         for e, n in enumerate(ctx.counts):
             if not n:
-                dts.append(None); dws.append(None)
+                dws.append(None)
                 continue
-            d = dout[o:o + n]
-            dts.append(ops.conv1x1(d, ws[e], None, None, True))
-            g = ops.gram(d, ts[e], 1, True)[0].reshape(ws[e].shape)
+            g = ops.gram(dout[o:o + n], ts[e], 1, True)[0].reshape(ws[e].shape)
             if ctx.mg[e] is not None:
                 ctx.mg[e].add_(g)
                 g = None
             dws.append(g)
             o += n
-        return (dout, None) + tuple(dts) + tuple(dws)
+        return (dout, None, None, None) + tuple(dts) + tuple(dws)
 
 
 # ======================================================================================
@@ -378,7 +452,10 @@ class ModExpert(nn.Module):
 
     def process(self, x, shared):
         t = self.inner(x, shared)
-        return _apply(_ExpertsOutFn, x, (x.shape[0],), t, self.proj[2].weight)       # proj[2](t) + x in one GEMM epilogue
+        n = x.shape[0]
+        cnt = torch.tensor([n], dtype=torch.int32, device=x.device)
+        off = torch.zeros(1, dtype=torch.int32, device=x.device)
+        return _apply(_ExpertsOutFn, x, (n,), cnt, off, t, self.proj[2].weight)      # proj[2](t) + x in one GEMM epilogue
 
     def forward(self, x, shared):
         if x.shape[0] == 0:
@@ -471,15 +548,18 @@ class AdapterLayer(nn.Module):
     def forward(self, x, freq_emb, shared):
         gates, idx, vals, aux, row_gate, tb = self.routing.route(x, freq_emb)
         self.loss = aux[0] if self.training else 0
-        counts = tuple(tb.counts.tolist())            # E segment sizes: the ragged expert launches are enqueued from the host
+        # E segment sizes: only the experts' BODIES (FFTAttention: ragged tensors) still need them on the host; the three 1x1
+        # projections of all experts are grouped launches that read the sizes from the router's device tables
+        counts = tuple(tb.counts.tolist())
+        E = len(counts)
         xrows = _RowsGatherFn.apply(x.contiguous(), tb.perm)
         srows = _RowsGatherFn.apply(shared.contiguous(), tb.perm)
-        inner: List[Optional[Tensor]] = []
-        o = 0
-        for e, n in enumerate(counts):
-            inner.append(self.experts[e][0].inner(xrows[o:o + n], srows[o:o + n]) if n else None)
-            o += n
-        rows_out = _apply(_ExpertsOutFn, xrows, counts, *inner, *[ex[0].proj[2].weight for ex in self.experts])
+        mods = [ex[0] for ex in self.experts]
+        ag = _apply(_ExpertsInFn, xrows, srows, counts, tb.counts, tb.offsets, *[m_.proj[0].weight for m_ in mods],
+                    *[m_.proj[1].weight for m_ in mods])
+        inner: List[Optional[Tensor]] = [
+            _apply(_EwiseFn, mods[e].body(ag[e]), ag[E + e], 1) if counts[e] else None for e in range(E)]
+        rows_out = _apply(_ExpertsOutFn, xrows, counts, tb.counts, tb.offsets, *inner, *[m_.proj[2].weight for m_ in mods])
         out = _RowsCombineFn.apply(rows_out, row_gate, tb.perm, x.shape[0])     # gate multiply + fp32 scatter-add (:116-124)
         return _c1(out.to(x.dtype), self.proj_out)
 

@@ -789,6 +789,30 @@ def moe_route_bwd(pooled: Tensor, freq: Tensor, wg: Tensor, wf: Tensor, noise: T
     return dpooled, dfreq, dwg, dwf
 
 
+def grouped_pw_gemm(problems, counts: Tensor, offsets: Tensor, max_rows: int, n_pix: int, dtype: torch.dtype) -> None:
+    """ONE launch for the 1x1 projections of all experts (csrc/grouped.hip).  ``problems``: list of dicts with keys
+    x, w (2-D fp32 [M, K] or, with transposed=True, [K, M] used as its transpose), y, m, k, expert and optionally bias, r,
+    x_local / y_local / r_local (the buffer is indexed by the row's position inside its expert's segment instead of the
+    stitched row number).  counts / offsets: the router's int32 DEVICE tables - no segment size is read by the host here."""
+    _gpu(counts, offsets)
+    assert counts.dtype == torch.int32 and offsets.dtype == torch.int32
+    arr = (L.GroupedProblem * len(problems))()
+    for i, q in enumerate(problems):
+        w = q["w"]
+        _f32(w, "expert weight")
+        g = arr[i]
+        g.x, g.x_rs = q["x"].data_ptr(), int(q.get("x_rs", 0))
+        g.w = w.data_ptr()
+        g.w_sm, g.w_sk = (1, w.stride(0)) if q.get("transposed") else (w.stride(0), 1)
+        g.bias = _p(q.get("bias"))
+        g.r, g.r_rs = _p(q.get("r")), int(q.get("r_rs", 0))
+        g.y, g.y_rs = q["y"].data_ptr(), int(q.get("y_rs", 0))
+        g.m, g.k, g.expert = int(q["m"]), int(q["k"]), int(q["expert"])
+        g.x_local, g.y_local, g.r_local = int(bool(q.get("x_local"))), int(bool(q.get("y_local"))), int(bool(q.get("r_local")))
+    L.check(L.lib().mi_grouped_pw_gemm(arr, len(problems), _p(counts), _p(offsets), int(max_rows), int(n_pix),
+                                       L.MI_BF16 if dtype == torch.bfloat16 else L.MI_F32, _stream()), "grouped_pw_gemm")
+
+
 def _bstride(t: Tensor) -> int:
     """Batch stride (elements) of a [B,C,H,W] tensor whose [C,H,W] block is dense (a channel slice of a wider tensor)."""
     B, Cc, H, W = t.shape

@@ -43,7 +43,13 @@ def _schema(tensors: Sequence[str], opt: Sequence[bool], tail: str) -> str:
 
 
 def _e(like: Tensor) -> Tensor:
-    return like.new_empty(0)
+    """Placeholder for an absent tensor in an op's Tensor[] output: one int8 element (no real output has that dtype; a
+    zero-size tensor would do, but zero-size outputs all share the null storage and trip the alias checks of opcheck)."""
+    return like.new_empty(1, dtype=torch.int8)
+
+
+def _absent(t: Tensor) -> bool:
+    return t.dtype == torch.int8
 
 
 def _pack(saved: Sequence[Optional[Tensor]], like: Tensor) -> List[Tensor]:
@@ -51,7 +57,7 @@ def _pack(saved: Sequence[Optional[Tensor]], like: Tensor) -> List[Tensor]:
 
 
 def _unpack(saved: Sequence[Tensor]) -> List[Optional[Tensor]]:
-    return [t if t.numel() else None for t in saved]
+    return [None if _absent(t) else t for t in saved]
 
 
 # Hand-off of the trainer's gradient buffers around the dispatcher (the ops' tensor arguments reach the op bodies as plain
@@ -108,10 +114,16 @@ def _register(name: str, fwd_schema: str, bwd_schema: str, fwd_impl, fwd_fake, b
         # The tensors autograd hands to setup_context are not the caller's Parameter objects, so the trainer's per-parameter
         # ``main_grad`` buffers (attributes of those objects) are picked up from the wrapper's hand-off (_MAIN_GRADS) instead.
         ctx.mg = _MAIN_GRADS.pop("next", None)
+        # only out (output 0) is differentiable: the saved tensors are outputs because the custom-op autograd contract wants
+        # them to be, and unused-gradient zeros must not be materialised for them (GB-sized memsets per block otherwise)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*output[1:])
         ctx.save_for_backward(*[v for v in lead if isinstance(v, Tensor)], *[p for p in params if p is not None], *output[1:])
 
     def backward(ctx, grads):
         dout = grads[0]
+        if dout is None:
+            return (None,) * (n_lead + n_params + n_tail)
         tens = list(ctx.saved_tensors)
         n_lt = sum(ctx.lead_is_tensor)
         n_pp = sum(ctx.n_params_present)
@@ -271,7 +283,7 @@ def _block_fwd_fake(x, heads, *rest):
     params, need = rest[:17], rest[17]
     out = torch.empty_like(x)
     if not need:
-        return [out] + [_e(x)] * 9
+        return [out] + [_e(x) for _ in range(9)]
     plan = R._block_plan(x, heads, params, need)
     att, ffn = params[2:9], params[11:17]
     return [out,

@@ -416,6 +416,30 @@ int mi_rows_dot(const float* g, const void* src, const int64_t* idx, float* out,
                 void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Grouped expert GEMM (csrc/grouped.hip): the 1x1 projections of all MoCE experts in ONE launch over a problem table whose
+ * ragged part - rows per expert, segment starts - is read from DEVICE memory (the router's counts / offsets tables), so no
+ * segment size has to reach the host for this stage.  Replaces the per-expert 1x1 calls of moce_ir.py:545-558 (ModExpert.process:
+ * proj[0], proj[1], proj[2]) as iterated by :666-672, whose split sizes the reference reads back with .tolist() (:88).
+ *   for every problem p, for i in [0, counts[p.expert]):
+ *       Y_p[row_y] = W_p . X_p[row_x] (+ bias_p) (+ R_p[row_r]),   row_* = i (local) or offsets[p.expert] + i (stitched buffers)
+ *   X rows are [K][N], Y / R rows [M][N] (N = H*W pixels, contiguous); W element (m, k) at w[m*w_sm + k*w_sk] (fp32; a
+ *   transposed use - the input gradient W^T dY - is just swapped strides); *_rs row strides in elements (0 = dense).
+ * Up to 16 problems per launch; the grid covers max_rows rows per problem, workgroups beyond an expert's count exit at once.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  const void* x; int64_t x_rs;
+  const float* w; int64_t w_sm, w_sk;
+  const float* bias;
+  const void* r; int64_t r_rs;
+  void* y; int64_t y_rs;
+  int m, k;
+  int expert;                     /* index into dev_counts / dev_offsets */
+  int x_local, y_local, r_local;  /* 1: the buffer is indexed by the row's position inside the expert's segment */
+} mi_grouped_problem;
+int mi_grouped_pw_gemm(const mi_grouped_problem* probs, int np, const int* dev_counts, const int* dev_offsets, int max_rows,
+                       int64_t N, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * MoCE router in one launch each way (moce_ir.py:684-800 RoutingFunction; :82-91 SparseDispatcher index bookkeeping).
  *   fwd: logits = pooled . Wg^T + freq . Wf^T  (pooled = GAP of the adapter input, [B,C]; freq = frequency embedding [B,F]);
  *        noisy = logits + noise / E  (noise: the caller's N(0,1) draw, [B,E], applied in train AND eval as the reference does);

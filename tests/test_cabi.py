@@ -159,9 +159,9 @@ def test_torch_library_custom_ops_are_registered(lib):
         assert outs[8].dtype == torch.uint8 and outs[8].numel() > 2 * 2 * 3 * c * 256 * 4  # the MDTA saved blob (mi_mdta_saved_bytes)
         res = torch.ops.mi_restore.transformer_block_bwd(outs[0], x, heads, *params, list(outs[1:]), False)
         assert len(res) == 18 and tuple(res[0].shape) == (2, c, 16, 16)
-        assert tuple(res[4].shape) == tuple(sd["attn.qkv.weight"].shape) and res[2].numel() == 0 or True
+        assert tuple(res[4].shape) == tuple(sd["attn.qkv.weight"].shape) and res[5].dtype == torch.int8   # qkv.bias absent (bias=False)
         nog = torch.ops.mi_restore.transformer_block_fwd(x, heads, *params, False)
-        assert all(t.numel() == 0 for t in nog[1:])
+        assert all(t.dtype == torch.int8 for t in nog[1:])          # placeholders for absent saved tensors
         y = torch.ops.mi_restore.layernorm_fwd(x, params[0], params[1], True)
         assert len(y) == 3 and tuple(y[1].shape) == (2, 256)
         a = torch.ops.mi_restore.mdta_fwd(x, heads, *params[2:9], True)

@@ -406,3 +406,49 @@ def test_decoder_block_at_real_planes_vs_oracle(dtype, tol, dim, heads, hw):
             worst = (name, e)
     # temperature / router gradients are differences of large sums: 10x the activation bound (as in the Restormer block tests)
     assert worst[1] < 10 * tol, worst
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_grouped_expert_gemm_reads_segments_from_device_tables(dtype, tol):
+    """csrc/grouped.hip: the projections of all experts in ONE launch; counts / offsets live on the device (the router's tables),
+    ranks differ per expert, one expert gets no rows, ragged plane (N not a multiple of the 64-pixel tile), local and stitched row
+    indexing, bias, residual and the transposed (input-gradient) weight use - against per-segment matmuls in fp64."""
+    from image_restoration_amd import ops
+    R_, Cc, H, W = 7, 48, 9, 21
+    N = H * W
+    counts = torch.tensor([3, 0, 1, 3], dtype=torch.int32)
+    offsets = torch.tensor([0, 3, 3, 4, 7], dtype=torch.int32)
+    ranks = [6, 12, 24, 48]
+    x = seeded_input((R_, Cc, H, W), 801).to(dtype)
+    res = seeded_input((R_, Cc, H, W), 802).to(dtype)
+    w0 = [seeded_input((r, Cc), 810 + e) * 0.2 for e, r in enumerate(ranks)]
+    w2 = [seeded_input((Cc, r), 820 + e) * 0.2 for e, r in enumerate(ranks)]
+    bias = [seeded_input((r,), 830 + e) for e, r in enumerate(ranks)]
+    xg, rg = x.to(DEV), res.to(DEV)
+    cg, og = counts.to(DEV), offsets.to(DEV)
+    w0g, w2g, bg = [w.to(DEV) for w in w0], [w.to(DEV) for w in w2], [b.to(DEV) for b in bias]
+    # stage 1: a_e = W0_e x[seg e] + b_e (local rows); stage 2: out[seg e] = W2_e a_e + res[seg e] (stitched rows)
+    a = [torch.full((max(int(counts[e]), 1), r, H, W), float("nan"), dtype=dtype, device=DEV) for e, r in enumerate(ranks)]
+    ops.grouped_pw_gemm([dict(x=xg, w=w0g[e], bias=bg[e], y=a[e], m=ranks[e], k=Cc, expert=e, y_local=True) for e in range(4)],
+                        cg, og, R_, N, dtype)
+    out = torch.full((R_, Cc, H, W), float("nan"), dtype=dtype, device=DEV)
+    ops.grouped_pw_gemm([dict(x=a[e], w=w2g[e], r=rg, y=out, m=Cc, k=ranks[e], expert=e, x_local=True) for e in range(4)],
+                        cg, og, R_, N, dtype)
+    # input-gradient form: dx[seg e] = W0_e^T a_e
+    dx = torch.full((R_, Cc, H, W), float("nan"), dtype=dtype, device=DEV)
+    ops.grouped_pw_gemm([dict(x=a[e], w=w0g[e], transposed=True, y=dx, m=Cc, k=ranks[e], expert=e, x_local=True) for e in range(4)],
+                        cg, og, R_, N, dtype)
+    for e in range(4):
+        n, o = int(counts[e]), int(offsets[e])
+        if not n:
+            assert bool(torch.isnan(a[e].float()).all())                     # an expert without rows writes nothing
+            continue
+        xs = x[o:o + n].double().reshape(n, Cc, N)
+        ar = torch.einsum("mk,nkp->nmp", w0[e].double(), xs) + bias[e].double()[None, :, None]
+        assert rel(a[e][:n].reshape(n, ranks[e], N), ar) < tol, (e, "a")
+        a_used = a[e][:n].double().cpu().reshape(n, ranks[e], N)               # what stage 2 actually read (dtype-rounded)
+        outr = torch.einsum("mk,nkp->nmp", w2[e].double(), a_used) + res[o:o + n].double().reshape(n, Cc, N)
+        assert rel(out[o:o + n].reshape(n, Cc, N), outr) < tol, (e, "out")
+        dxr = torch.einsum("km,nkp->nmp", w0[e].double(), a_used)
+        assert rel(dx[o:o + n].reshape(n, Cc, N), dxr) < tol, (e, "dx")
+    assert not bool(torch.isnan(out.float()).any()) and not bool(torch.isnan(dx.float()).any())
