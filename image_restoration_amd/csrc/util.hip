@@ -30,7 +30,7 @@ static void env_load() {
   };
   for (int i = 0; i < E_ENV_COUNT; ++i) {
     const char* e = getenv(names[i]);
-    g_env.set[i] = e != nullptr;
+    g_env.set[i] = e != nullptr && e[0] != 0;          // set-but-empty counts as unset (the Python side reads it the same way)
     g_env.val[i][0] = 0;
     if (e) { strncpy(g_env.val[i], e, sizeof(g_env.val[i]) - 1); g_env.val[i][sizeof(g_env.val[i]) - 1] = 0; }
   }

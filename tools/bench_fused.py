@@ -55,6 +55,45 @@ def gdfn():
               f"{flops / tf / 1e6:6.1f} TF/s)   chain {tc:8.1f} us   speed-up {tc / tf:4.2f}x", flush=True)
 
 
+def mdta():
+    """Fused pass A (LN -> qkv -> dw3x3 -> q k^T partials + v) + partial sum + fold + M v, against the unfused chain
+    (qkv GEMM with LN on load, dw3x3, streaming Gram, fold, M v)."""
+    import image_restoration_amd as m
+    for C, heads, H, W in ((48, 1, 256, 256), (96, 2, 128, 128), (96, 1, 256, 256)):
+        torch.manual_seed(0)
+        x = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16)
+        ln_w = 1 + 0.1 * torch.randn(C, device=DEV)
+        ln_b = 0.1 * torch.randn(C, device=DEV)
+        att = (torch.ones(heads, 1, 1, device=DEV), torch.randn(3 * C, C, 1, 1, device=DEV) / C ** 0.5, None,
+               torch.randn(3 * C, 1, 3, 3, device=DEV) / 3, None, torch.randn(C, C, 1, 1, device=DEV) / C ** 0.5, None)
+        pack = ops.mdta_fused_pack(x, heads, ln_w, ln_b, att)
+        fused = lambda: ops.mdta_fused_fwd(x, pack, att, heads, True, x)
+        chain = lambda: ops.mdta_fwd(x, x, att, heads, False, ln=(ln_w, ln_b, False))
+        if os.environ.get("BF_ABLATE"):
+            for name, flag in (("full", 0), ("no GEMM1", 32), ("no conv", 64), ("no Gram", 128), ("no GEMM1/conv", 96),
+                               ("prologue + LN only", 224)):
+                os.environ["MI_FM_DEBUG"] = str(flag)
+                m.reload_env()
+                print(f"   ablation C={C} heads={heads} {H}x{W}: {name:20s} {timeit(fused):8.1f} us (whole half-block)", flush=True)
+            os.environ["MI_FM_DEBUG"] = "0"
+            m.reload_env()
+        ops.prof_enable(True)
+        for _ in range(5):
+            fused()
+        torch.cuda.synchronize()
+        tab = ops.prof_collect()
+        ops.prof_enable(False)
+        ka = tab["mdta_fused_a"]
+        t_a = ka["ms"] / ka["launches"] * 1e3
+        tf, tc = timeit(fused), timeit(chain)
+        N = float(B) * H * W
+        fl = 2.0 * N * (3.0 * C * C + C * (C / heads))
+        print(f"mdta fwd C={C} heads={heads} {H}x{W} bs={B}: half-block fused {tf:8.1f} us  chain {tc:8.1f} us  speed-up {tc / tf:4.2f}x | "
+              f"pass A kernel alone {t_a:8.1f} us = {2.0 * N * C * 2 / t_a / 1e6:5.2f} TB/s algorithmic (x in, v out), "
+              f"{fl / t_a / 1e6:6.1f} TF/s MFMA ({fl / t_a / 1e6 / 2500 * 100:4.1f} % of the bf16 peak); "
+              f"others: " + ", ".join(f"{k} {v['ms'] / 5 * 1e3:.0f} us" for k, v in tab.items() if k != "mdta_fused_a"), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "gdfn"
-    {"gdfn": gdfn}[which]()
+    {"gdfn": gdfn, "mdta": mdta}[which]()

@@ -17,8 +17,10 @@ torch.manual_seed(0)
 net = m.Restormer(**configs.RESTORMER_BASE).to(dev)
 clean = torch.rand((1, 3, size, size), device=dev)
 noisy = torch.clamp(torch.round(clean * 255) + 25 * torch.randn_like(clean), 0, 255) / 255
-for fused in (1, 0):
+for fused in (2, 1, 0):
     os.environ["MI_NO_FUSED_INFER"] = "" if fused else "1"
+    os.environ["MI_NO_FUSED_MDTA"] = "" if fused == 2 else "1"
+    m.reload_env()
     for tb in (8, 25):
         out = inference.tiled_restore(net, noisy, tile_batch=tb)
         torch.cuda.synchronize()
@@ -29,7 +31,7 @@ for fused in (1, 0):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         p, s, _ = metrics.compute_psnr_ssim(out, clean)
-        print(f"tiled inference {size}x{size}, 224+2x16 tiles, tile_batch {tb}, fused LN+GDFN {'on' if fused else 'off'}: "
+        print(f"tiled inference {size}x{size}, 224+2x16 tiles, tile_batch {tb}, fused {['none', 'LN+GDFN', 'LN+GDFN and MDTA pass A'][fused]}: "
               f"{dt * 1e3:8.1f} ms/image = {size * size / dt / 1e6:6.2f} Mpix/s   (random-init net: PSNR {p:.2f} dB, SSIM {s:.4f}; "
               f"peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
 
@@ -49,6 +51,8 @@ def psnr(a, b):
 
 
 os.environ["MI_NO_FUSED_INFER"] = ""
+os.environ["MI_NO_FUSED_MDTA"] = ""
+m.reload_env()
 with inference.PackedWeights(net):
     outp, dtp = timed(25)
 out0, dt0 = timed(25)
