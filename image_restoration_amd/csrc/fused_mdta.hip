@@ -44,32 +44,30 @@ template <int C_, int HEADS_, int TH_, int NW_> struct FmCfg {
   static constexpr int NV = 8 * KS32 + 4 * KT16;
   static constexpr int W1S = C + 8;
   static constexpr int CH = 16;                          // channels per chunk
-  static constexpr int PC = 8;                           // "pairs" per chunk: channels r and r + 8 ride in one packed lane
   static constexpr int NB = C / 16;                      // 16-row blocks of q (= of k, = of v)
   static constexpr int NCHUNK = 3 * NB;                  // chunk order: k blocks, q blocks, v blocks
-  static constexpr int CB = c / 16;                      // column (k) blocks per head
-  static constexpr int NCBW = (CB + NW - 1) / NW;        // column blocks of a head owned by one wave
-  static constexpr int NQD = (NB + NW - 1) / NW;         // q diagonal blocks per wave
+  static constexpr int CB = c / 16;                      // column (k) blocks per head: block cb belongs to wave cb
+  static constexpr int NQD = (NB + 1) / 2;               // q diagonal blocks per diagonal wave (waves NW-2, NW-1)
   static constexpr int VPR = TW / 8;
-  static constexpr int CG = TW / 8;                      // conv: lanes per tile row
-  static constexpr int RPP = 64 / CG;
-  static constexpr int ROWS = TH < RPP ? TH : RPP;
-  static constexpr int NPAIR = RPP / ROWS;
-  static constexpr int PASSES = TH / ROWS;
-  static constexpr int PPW = PC / NW;
   static constexpr int FRAG = 1024;                      // bytes of one operand fragment (16 channels x 32 pixels)
-  static constexpr int H0_BYTES = CH * PLANE * 2;
+  static constexpr int H0_BYTES = CH * PLANE * 2;        // one h0 chunk buffer (two of them)
   static constexpr int KT_BYTES = NB * TH * FRAG;
-  static constexpr int QC_BYTES = TH * FRAG;
-  static constexpr int W1_BYTES = CH * W1S * 2;
-  static constexpr int WD_BYTES = PC * 20 * 4;           // taps + bias of a chunk (two buffers)
-  static constexpr int S_BYTES = C * PLANE * 2;          // prologue: raw x staged plane-major (aliases everything)
-  static constexpr int MAIN_BYTES = H0_BYTES + KT_BYTES + QC_BYTES + W1_BYTES + 2 * WD_BYTES;
-  static constexpr int LDS_BYTES = MAIN_BYTES > S_BYTES ? MAIN_BYTES : S_BYTES;
-  static_assert(C % 16 == 0 && c % 16 == 0 && NW == 4 && TH % ROWS == 0 && PPW % NPAIR == 0 && PC % NW == 0, "unsupported tile");
+  static constexpr int QC_BYTES = TH * FRAG;             // one q chunk buffer (two of them)
+  static constexpr int W1_BYTES = NCHUNK * CH * W1S * 2; // ALL chunks' weights, resident for the workgroup's life
+  static constexpr int WD_BYTES = NCHUNK * CH * 10 * 4;  // depthwise taps + bias [chunk][16][10] fp32
+  static constexpr int S_BYTES = C * PLANE * 2;          // raw x of a tile, staged plane-major: aliases the h0 buffers + K image
+  static constexpr int HK_BYTES = 2 * H0_BYTES + KT_BYTES;
+  static constexpr int A_BYTES = HK_BYTES > S_BYTES ? HK_BYTES : S_BYTES;
+  static constexpr int LDS_BYTES = A_BYTES + 2 * QC_BYTES + W1_BYTES + WD_BYTES;
+  static constexpr int NBV = C * HR * VPR;               // 16-byte vectors of a tile body (rows y0-1 .. y0+TH)
+  static constexpr int NBN = (NBV + NT - 1) / NT;
+  static constexpr int NE = HPXP - BODY;                 // halo-column pixels + padding per plane
+  static constexpr int NEN = (C * NE + NT - 1) / NT;
+  static_assert(C % 16 == 0 && c % 16 == 0 && NW == 8 && TH == 8, "unsupported tile");
+  static_assert(CB <= NW - 2, "waves NW-2 / NW-1 take the q diagonal blocks");
   static_assert(4 * MTW <= 64, "validity mask");
-  static_assert(H0_BYTES % 16 == 0 && W1_BYTES % 16 == 0, "LDS carve alignment");
-  static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert(A_BYTES % 16 == 0 && W1_BYTES % 16 == 0 && WD_BYTES % 16 == 0, "LDS carve alignment");
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
 struct FmArgs {
@@ -79,14 +77,14 @@ struct FmArgs {
   int B, H, W, with_bias, tiles_x, tiles_y, S, dbg;
 };
 
-// packed-weight blob: W1p [NCHUNK][16][C + 8] bf16 (fp32 bias in the row padding), WDp [NCHUNK][8][10][2] fp32
+// packed-weight blob: W1p [NCHUNK][16][C + 8] bf16 (fp32 bias in the row padding), WDp [NCHUNK][16][10] fp32 (taps, bias)
 struct FmPackLayout { size_t w1p, wdp, bytes; int nchunk; };
 static FmPackLayout fm_pack_layout(int C) {
   FmPackLayout l;
   l.nchunk = 3 * C / 16;
   size_t off = 0;
   l.w1p = off; off = align_up(off + (size_t)l.nchunk * 16 * (C + 8) * 2, 256);
-  l.wdp = off; off = align_up(off + (size_t)l.nchunk * 8 * 20 * 4, 256);
+  l.wdp = off; off = align_up(off + (size_t)l.nchunk * 16 * 10 * 4, 256);
   l.bytes = off;
   return l;
 }
@@ -105,7 +103,7 @@ struct FmPackArgs {
 };
 __global__ __launch_bounds__(256) void fm_pack_kernel(FmPackArgs a) {
   const int C = a.C, W1S = C + 8;
-  const int64_t n_w1 = (int64_t)a.nchunk * 16 * W1S, n_wd = (int64_t)a.nchunk * 8 * 20;
+  const int64_t n_w1 = (int64_t)a.nchunk * 16 * W1S, n_wd = (int64_t)a.nchunk * 16 * 10;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_w1 + n_wd; e += (int64_t)gridDim.x * 256) {
     if (e < n_w1) {
       const int k = (int)(e % W1S);
@@ -124,12 +122,11 @@ __global__ __launch_bounds__(256) void fm_pack_kernel(FmPackArgs a) {
       }
       continue;
     }
-    const int64_t r0 = e - n_w1;                       // [chunk][pair][tap 0..8, bias][half]
-    const int half = (int)(r0 % 2);
-    int64_t q = r0 / 2;
-    const int tp = (int)(q % 10); q /= 10;
-    const int p = (int)(q % 8), ci = (int)(q / 8);
-    const int ch = fm_channel(C, ci, p + 8 * half);
+    const int64_t r0 = e - n_w1;                       // [chunk][row 0..15][tap 0..8, bias]
+    const int tp = (int)(r0 % 10);
+    const int64_t q = r0 / 10;
+    const int r = (int)(q % 16), ci = (int)(q / 16);
+    const int ch = fm_channel(C, ci, r);
     a.wdp[r0] = tp < 9 ? a.dw_w[(int64_t)ch * 9 + tp] : (a.dw_b ? a.dw_b[ch] : 0.f);
   }
 }
@@ -146,16 +143,64 @@ __device__ __forceinline__ s16x8 fm_ldfrag(const unsigned char* base, int trow, 
   return *reinterpret_cast<const s16x8*>(base + trow * 1024 + (oct * 16 + fm_slot(row, trow, oct)) * 16);
 }
 
+// The next tile's raw x (tile + halo) travels global -> registers while the current tile's v chunks are computed, and
+// registers -> LDS once the current tile is done: the HBM latency of the staging hides behind compute.
+template <typename K> struct FmStage { u32x4 raw[K::NBN]; u16 rawe[K::NEN]; };
+
+template <typename K>
+__device__ __forceinline__ void fm_stage_load(FmStage<K>& st, const bf16* xb, int tt, int x0, int y0, int H, int W, int64_t HW) {
+#pragma unroll
+  for (int n = 0; n < K::NBN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+    const int Y = y0 - 1 + r;
+    st.raw[n] = (u32x4){0u, 0u, 0u, 0u};
+    if (idx < K::NBV && Y >= 0 && Y < H)
+      st.raw[n] = *reinterpret_cast<const u32x4*>(xb + (int64_t)cc * HW + (int64_t)Y * W + x0 + 8 * u);
+  }
+#pragma unroll
+  for (int n = 0; n < K::NEN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / K::NE, k = idx - cc * K::NE;
+    st.rawe[n] = 0;
+    if (idx < K::C * K::NE && k < 2 * K::HR) {
+      const int side = k >= K::HR ? 1 : 0, r = k - side * K::HR;
+      const int Y = y0 - 1 + r, X = side ? x0 + K::TW : x0 - 1;
+      if (Y >= 0 && Y < H && X >= 0 && X < W)
+        st.rawe[n] = reinterpret_cast<const u16*>(xb)[(int64_t)cc * HW + (int64_t)Y * W + X];
+    }
+  }
+}
+template <typename K>
+__device__ __forceinline__ void fm_stage_store(const FmStage<K>& st, bf16* S, int tt) {
+#pragma unroll
+  for (int n = 0; n < K::NBN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+    if (idx < K::NBV) *reinterpret_cast<u32x4*>(&S[cc * K::PLANE + r * K::TW + 8 * u]) = st.raw[n];
+  }
+#pragma unroll
+  for (int n = 0; n < K::NEN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / K::NE, k = idx - cc * K::NE;
+    if (idx < K::C * K::NE) reinterpret_cast<u16*>(S)[cc * K::PLANE + K::BODY + k] = st.rawe[n];
+  }
+}
+
+// One 8-wave workgroup per CU walks a contiguous range of one image's TH x 32 tiles.  Resident for its whole life: the packed
+// weights of all 3C output channels (LDS), its share of the Gram accumulators (registers).  Per tile, per 16-channel chunk:
+//   GEMM1(ci) -> H0[ci & 1]   |barrier|   Gram(ci - 1, if that was a q chunk)   conv(ci) -> K image / Q[ci & 1] / HBM
+// ONE barrier per chunk: the h0 and q buffers are double-buffered, so a wave may run one phase ahead of the slowest.
 template <int C, int HEADS, int TH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
   using K = FmCfg<C, HEADS, TH, NW>;
   constexpr int NT = K::NT, TW = K::TW;
   extern __shared__ __attribute__((aligned(16))) unsigned char fm_lds[];
-  bf16* const H0 = reinterpret_cast<bf16*>(fm_lds);
-  unsigned char* const KT = fm_lds + K::H0_BYTES;
-  unsigned char* const QC = KT + K::KT_BYTES;
-  bf16* const W1 = reinterpret_cast<bf16*>(QC + K::QC_BYTES);
-  float* const WD = reinterpret_cast<float*>(QC + K::QC_BYTES + K::W1_BYTES);     // [2][PC][20]
+  bf16* const H0 = reinterpret_cast<bf16*>(fm_lds);                       // [2][16][PLANE]
+  unsigned char* const KT = fm_lds + 2 * K::H0_BYTES;                     // [NB][TH][FRAG]
+  unsigned char* const QC = fm_lds + K::A_BYTES;                          // [2][TH][FRAG]
+  bf16* const W1 = reinterpret_cast<bf16*>(QC + 2 * K::QC_BYTES);         // [NCHUNK][16][W1S]
+  float* const WD = reinterpret_cast<float*>(QC + 2 * K::QC_BYTES + K::W1_BYTES);   // [NCHUNK][16][10]
   bf16* const S = reinterpret_cast<bf16*>(fm_lds);
   const int t = threadIdx.x, lane_outer = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -165,67 +210,28 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
   const int64_t HW = (int64_t)a.H * a.W;
   const bf16* const xb = a.x + (int64_t)b * C * HW;
 
-  f32x4 acc[K::NB][K::NCBW], kd[HEADS][K::NCBW], qd[K::NQD];
+  f32x4 acc[K::NB], kd[HEADS], qd[K::NQD];
 #pragma unroll
-  for (int i = 0; i < K::NB; ++i)
+  for (int i = 0; i < K::NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < K::NCBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < HEADS; ++i)
-#pragma unroll
-    for (int j = 0; j < K::NCBW; ++j) kd[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < HEADS; ++i) kd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < K::NQD; ++i) qd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  FmStage<K> stg;
+  if (t0 < t1) fm_stage_load<K>(stg, xb, t, (t0 % a.tiles_x) * TW, (t0 / a.tiles_x) * TH, a.H, a.W, HW);
+  {                                                       // the weights of every chunk: global -> LDS, once
+    const u32x4* s1 = reinterpret_cast<const u32x4*>(a.w1p);
+    for (int vv = t; vv < K::W1_BYTES / 16; vv += NT) reinterpret_cast<u32x4*>(W1)[vv] = s1[vv];
+    const u32x4* s2 = reinterpret_cast<const u32x4*>(a.wdp);
+    for (int vv = t; vv < K::WD_BYTES / 16; vv += NT) reinterpret_cast<u32x4*>(WD)[vv] = s2[vv];
+  }
 
   for (int tile = t0; tile < t1; ++tile) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
-    int lane_o = lane_outer;
-    asm volatile("" : "+v"(lane_o));                    // per-tile lane coordinates: nothing derived from them is hoisted
-    const int lane = lane_o, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
-    const int tt = wv * 64 + lane;
-    // ---------------------------------------------------------------- stage raw x (tile + halo), plane-major
-    {
-      constexpr int NBV = C * K::HR * K::VPR;           // 16-byte vectors of the tile body
-      constexpr int NBN = (NBV + NT - 1) / NT;
-      constexpr int NE = K::HPXP - K::BODY;             // halo-column pixels + padding per plane
-      constexpr int NEN = (C * NE + NT - 1) / NT;
-      u32x4 raw[NBN];
-      u16 rawe[NEN];
-#pragma unroll
-      for (int n = 0; n < NBN; ++n) {
-        const int idx = tt + NT * n;
-        const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
-        const int Y = y0 - 1 + r;
-        raw[n] = (u32x4){0u, 0u, 0u, 0u};
-        if (idx < NBV && Y >= 0 && Y < a.H)
-          raw[n] = *reinterpret_cast<const u32x4*>(xb + (int64_t)cc * HW + (int64_t)Y * a.W + x0 + 8 * u);
-      }
-#pragma unroll
-      for (int n = 0; n < NEN; ++n) {
-        const int idx = tt + NT * n;
-        const int cc = idx / NE, k = idx - cc * NE;
-        rawe[n] = 0;
-        if (idx < C * NE && k < 2 * K::HR) {
-          const int side = k >= K::HR ? 1 : 0, r = k - side * K::HR;
-          const int Y = y0 - 1 + r, X = side ? x0 + TW : x0 - 1;
-          if (Y >= 0 && Y < a.H && X >= 0 && X < a.W)
-            rawe[n] = reinterpret_cast<const u16*>(xb)[(int64_t)cc * HW + (int64_t)Y * a.W + X];
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < NBN; ++n) {
-        const int idx = tt + NT * n;
-        const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
-        if (idx < NBV) *reinterpret_cast<u32x4*>(&S[cc * K::PLANE + r * TW + 8 * u]) = raw[n];
-      }
-#pragma unroll
-      for (int n = 0; n < NEN; ++n) {
-        const int idx = tt + NT * n;
-        const int cc = idx / NE, k = idx - cc * NE;
-        if (idx < C * NE) reinterpret_cast<u16*>(S)[cc * K::PLANE + K::BODY + k] = rawe[n];
-      }
-    }
+    __syncthreads();                                      // every wave is done with the previous tile: the aliased region is free
+    fm_stage_store<K>(stg, S, t);
     __syncthreads();
 
     // ---------------------------------------------------------------- LN(x) -> A-operand fragments (registers)
@@ -233,109 +239,111 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
     s16x8 xa[K::MTW][K::KS32 > 0 ? K::KS32 : 1];
     s16x8 xt[K::MTW];
     unsigned long long vmask = 0;
+    {
+      int lane_o = lane_outer;
+      asm volatile("" : "+v"(lane_o));
+      const int lane = lane_o, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
 #pragma unroll
-    for (int i = 0; i < K::MTW; ++i) {
-      const int mt = wv + NW * i;
-      if (mt < K::MT) {
-        const bf16* sp_ = &S[(4 * g + qq) * K::PLANE + mt * 16 + 4 * pp];
-        s16x4 lo[K::KS32 > 0 ? K::KS32 : 1], hi[K::KS32 > 0 ? K::KS32 : 1], tl = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
+      for (int i = 0; i < K::MTW; ++i) {
+        const int mt = wv + NW * i;
+        if (mt < K::MT) {
+          const bf16* sp_ = &S[(4 * g + qq) * K::PLANE + mt * 16 + 4 * pp];
+          s16x4 lo[K::KS32 > 0 ? K::KS32 : 1], hi[K::KS32 > 0 ? K::KS32 : 1], tl = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < K::KS32; ++ks) {
-          lo[ks] = tr_b16(sp_ + (ks * 32) * K::PLANE);
-          hi[ks] = tr_b16(sp_ + (ks * 32 + 16) * K::PLANE);
-        }
-        if (K::KT16) tl = tr_b16(sp_ + (K::KS32 * 32) * K::PLANE);
-        if constexpr (K::KS32 == 3) lds_wait(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], tl, dm);
-        else if constexpr (K::KS32 == 2) lds_wait(lo[0], hi[0], lo[1], hi[1], tl, dm);
-        else if constexpr (K::KS32 == 1) lds_wait(lo[0], hi[0], tl, dm);
-        else lds_wait(tl);
-        float v[K::NV];
+          for (int ks = 0; ks < K::KS32; ++ks) {
+            lo[ks] = tr_b16(sp_ + (ks * 32) * K::PLANE);
+            hi[ks] = tr_b16(sp_ + (ks * 32 + 16) * K::PLANE);
+          }
+          if (K::KT16) tl = tr_b16(sp_ + (K::KS32 * 32) * K::PLANE);
+          if constexpr (K::KS32 == 3) lds_wait(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], tl, dm);
+          else if constexpr (K::KS32 == 2) lds_wait(lo[0], hi[0], lo[1], hi[1], tl, dm);
+          else if constexpr (K::KS32 == 1) lds_wait(lo[0], hi[0], tl, dm);
+          else lds_wait(tl);
+          float v[K::NV];
 #pragma unroll
-        for (int ks = 0; ks < K::KS32; ++ks)
+          for (int ks = 0; ks < K::KS32; ++ks)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { v[8 * ks + j] = bf_s(lo[ks][j]); v[8 * ks + 4 + j] = bf_s(hi[ks][j]); }
-        if (K::KT16)
+            for (int j = 0; j < 4; ++j) { v[8 * ks + j] = bf_s(lo[ks][j]); v[8 * ks + 4 + j] = bf_s(hi[ks][j]); }
+          if (K::KT16)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[8 * K::KS32 + j] = bf_s(tl[j]);
-        float s = 0.f;
+            for (int j = 0; j < 4; ++j) v[8 * K::KS32 + j] = bf_s(tl[j]);
+          float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < K::NV; ++j) s += v[j];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float mu = s * (1.0f / C);
-        float q = 0.f;
+          for (int j = 0; j < K::NV; ++j) s += v[j];
+          s += __shfl_xor(s, 16);
+          s += __shfl_xor(s, 32);
+          const float mu = s * (1.0f / C);
+          float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < K::NV; ++j) { const float d = v[j] - mu; q += d * d; }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
-        const float sub = a.with_bias ? mu : 0.f;       // BiasFree: x / sqrt(var + eps), x not centred (Restormer.py:37-39)
+          for (int j = 0; j < K::NV; ++j) { const float d = v[j] - mu; q += d * d; }
+          q += __shfl_xor(q, 16);
+          q += __shfl_xor(q, 32);
+          const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+          const float sub = a.with_bias ? mu : 0.f;     // BiasFree: x / sqrt(var + eps), x not centred (Restormer.py:37-39)
 #pragma unroll
-        for (int j = 0; j < K::NV; ++j) v[j] = (v[j] - sub) * rstd;
+          for (int j = 0; j < K::NV; ++j) v[j] = (v[j] - sub) * rstd;
 #pragma unroll
-        for (int ks = 0; ks < K::KS32; ++ks)
+          for (int ks = 0; ks < K::KS32; ++ks)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xa[i][ks][j] = bf_bits(v[8 * ks + j]);
-        xt[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (K::KT16)
+            for (int j = 0; j < 8; ++j) xa[i][ks][j] = bf_bits(v[8 * ks + j]);
+          xt[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (K::KT16)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xt[i][j] = bf_bits(v[8 * K::KS32 + j]);
-        if (a.mean && g == 0) {                         // statistics of the tile's own pixels
-          const int ipx = mt * 16 + li;
-          if (ipx < K::BODY) {
-            const int rr = ipx / TW, col = ipx % TW;
-            if (rr >= 1 && rr <= TH) {
-              const int64_t o = (int64_t)b * HW + (int64_t)(y0 - 1 + rr) * a.W + x0 + col;
-              a.mean[o] = mu; a.rstd[o] = rstd;
+            for (int j = 0; j < 4; ++j) xt[i][j] = bf_bits(v[8 * K::KS32 + j]);
+          if (a.mean && g == 0) {                       // statistics of the tile's own pixels
+            const int ipx = mt * 16 + li;
+            if (ipx < K::BODY) {
+              const int rr = ipx / TW, col = ipx % TW;
+              if (rr >= 1 && rr <= TH) {
+                const int64_t o = (int64_t)b * HW + (int64_t)(y0 - 1 + rr) * a.W + x0 + col;
+                a.mean[o] = mu; a.rstd[o] = rstd;
+              }
             }
           }
-        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ipx = mt * 16 + 4 * g + r;
-          bool ok;
-          if (ipx < K::BODY) { const int Y = y0 - 1 + ipx / TW; ok = Y >= 0 && Y < a.H; }
-          else if (ipx < K::HPX) {
-            const int k = ipx - K::BODY, side = k >= K::HR ? 1 : 0, rr = k - side * K::HR;
-            const int Y = y0 - 1 + rr, X = side ? x0 + TW : x0 - 1;
-            ok = Y >= 0 && Y < a.H && X >= 0 && X < a.W;
-          } else ok = false;
-          vmask |= (ok ? 1ull : 0ull) << (4 * i + r);
-        }
-      } else {
+          for (int r = 0; r < 4; ++r) {
+            const int ipx = mt * 16 + 4 * g + r;
+            bool ok;
+            if (ipx < K::BODY) { const int Y = y0 - 1 + ipx / TW; ok = Y >= 0 && Y < a.H; }
+            else if (ipx < K::HPX) {
+              const int k = ipx - K::BODY, side = k >= K::HR ? 1 : 0, rr = k - side * K::HR;
+              const int Y = y0 - 1 + rr, X = side ? x0 + TW : x0 - 1;
+              ok = Y >= 0 && Y < a.H && X >= 0 && X < a.W;
+            } else ok = false;
+            vmask |= (ok ? 1ull : 0ull) << (4 * i + r);
+          }
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < K::KS32; ++ks) xa[i][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        xt[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          for (int ks = 0; ks < K::KS32; ++ks) xa[i][ks] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          xt[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
       }
     }
-    __syncthreads();                                    // the staged x is dead: the region becomes h0 / K / Q / weights
-
-    constexpr int W1V = K::W1_BYTES / 16, WDV = K::WD_BYTES / 16;
-    constexpr int W1N = (W1V + NT - 1) / NT;
-    static_assert(WDV <= NT, "one vector per thread");
-    {
-      const u32x4* src = reinterpret_cast<const u32x4*>(a.w1p);
-      for (int vv = tt; vv < W1V; vv += NT) reinterpret_cast<u32x4*>(W1)[vv] = src[vv];
-      if (tt < WDV) reinterpret_cast<u32x4*>(WD)[tt] = reinterpret_cast<const u32x4*>(a.wdp)[tt];
-    }
-    __syncthreads();
+    __syncthreads();                                      // the staged x is dead: the region becomes the h0 buffers / the K image
 
 #pragma unroll 1
     for (int ci = 0; ci < K::NCHUNK; ++ci) {
       int lane_c = lane_outer;
       asm volatile("" : "+v"(lane_c));
-      const int lane = lane_c, li = lane & 15, g = lane >> 4, tt = wv * 64 + lane;
+      const int lane = lane_c, li = lane & 15, g = lane >> 4;
+      // the next tile's x leaves HBM while this tile's v chunks are computed
+      if (ci == 2 * K::NB && tile + 1 < t1) {
+        const int nt_ = tile + 1;
+        fm_stage_load<K>(stg, xb, wv * 64 + lane, (nt_ % a.tiles_x) * TW, (nt_ / a.tiles_x) * TH, a.H, a.W, HW);
+      }
+      bf16* const H0c = H0 + (ci & 1) * (K::CH * K::PLANE);
       // ------------------------------------------------------------ GEMM1: h0 chunk = W'[chunk] . LN(x), to LDS
       if (!(a.dbg & 32)) {
-        const bf16* wr = &W1[li * K::W1S + 4 * g];
+        const bf16* wrow = &W1[(ci * K::CH + li) * K::W1S];
+        const bf16* wr = wrow + 4 * g;
         s16x8 bw[K::KS32 > 0 ? K::KS32 : 1];
         s16x8 bt = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < K::KS32; ++ks)
           bw[ks] = cat8(*reinterpret_cast<const s16x4*>(wr + ks * 32), *reinterpret_cast<const s16x4*>(wr + ks * 32 + 16));
         if (K::KT16) bt = cat8(*reinterpret_cast<const s16x4*>(wr + K::KS32 * 32), (s16x4){0, 0, 0, 0});
-        const float bias = *reinterpret_cast<const float*>(&W1[li * K::W1S + C]);
-        bf16* hrow = &H0[li * K::PLANE + 4 * g];
+        const float bias = *reinterpret_cast<const float*>(wrow + C);
+        bf16* hrow = &H0c[li * K::PLANE + 4 * g];
 #pragma unroll
         for (int i = 0; i < K::MTW; ++i) {
           const int mt = wv + NW * i;
@@ -354,123 +362,30 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
       }
       __syncthreads();
 
-      // ------------------------------------------------------------ depthwise 3x3 (VALU); next chunk's weights in flight
-      {
-        u32x4 wr1[W1N], wrd = {0u, 0u, 0u, 0u};
-        const bool more = ci + 1 < K::NCHUNK;
-        const float* const wdc = WD + (ci & 1) * (K::PC * 20);
-        {
-          if (more && tt < WDV) wrd = reinterpret_cast<const u32x4*>(a.wdp + (int64_t)(ci + 1) * K::PC * 20)[tt];
-          const u32x4* s1 = reinterpret_cast<const u32x4*>(a.w1p + (int64_t)(ci + 1) * K::CH * K::W1S);
-#pragma unroll
-          for (int n = 0; n < W1N; ++n) { const int vv = tt + NT * n; if (more && vv < W1V) wr1[n] = s1[vv]; }
-        }
-        const int kind = ci < K::NB ? 0 : (ci < 2 * K::NB ? 1 : 2);            // 0: k, 1: q, 2: v
-        const int blk = ci - kind * K::NB;                                       // 16-row block of its kind
-        unsigned char* const img = kind == 0 ? KT + blk * (TH * K::FRAG) : QC;
-        const int cg = lane % K::CG, rl = (lane / K::CG) % K::ROWS, psel = lane / (K::CG * K::ROWS);
-#pragma unroll 1
-        for (int s = 0; s < ((a.dbg & 64) ? 0 : K::PPW / K::NPAIR); ++s) {
-          const int p = wv * K::PPW + s * K::NPAIR + psel;
-          const float* wp = wdc + p * 20;
-          f32x2 w[10];
-#pragma unroll
-          for (int i = 0; i < 10; ++i) {
-            if constexpr (K::NPAIR == 1) {
-              w[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i])));
-              w[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wp[2 * i + 1])));
-            } else {
-              w[i] = *reinterpret_cast<const f32x2*>(wp + 2 * i);
-            }
-          }
-          const bf16* h1 = &H0[p * K::PLANE];
-          const bf16* h2 = &H0[(K::PC + p) * K::PLANE];
-          const int eoff = K::BODY + (cg == K::CG - 1 ? K::HR : 0);
-#pragma unroll
-          for (int rp = 0; rp < K::PASSES; ++rp) {
-            const int row = rp * K::ROWS + rl;
-            f32x2 o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = w[9];
-#pragma unroll
-            for (int dr = 0; dr < 3; ++dr) {
-              const int rin = row + dr;
-              const u32x4 r1 = *reinterpret_cast<const u32x4*>(h1 + rin * TW + 8 * cg);
-              const u32x4 r2 = *reinterpret_cast<const u32x4*>(h2 + rin * TW + 8 * cg);
-              const u16 e1 = reinterpret_cast<const u16*>(h1)[eoff + rin];
-              const u16 e2 = reinterpret_cast<const u16*>(h2)[eoff + rin];
-              f32x2 v[10];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                v[1 + 2 * k][0] = bf_lo(r1[k]); v[2 + 2 * k][0] = bf_hi(r1[k]);
-                v[1 + 2 * k][1] = bf_lo(r2[k]); v[2 + 2 * k][1] = bf_hi(r2[k]);
-              }
-              f32x2 edge, lft, rgt;
-              edge[0] = bf_lo(e1); edge[1] = bf_lo(e2);
-              lft[0] = from_prev_lane(v[8][0]); lft[1] = from_prev_lane(v[8][1]);
-              rgt[0] = from_next_lane(v[1][0]); rgt[1] = from_next_lane(v[1][1]);
-              v[0] = cg == 0 ? edge : lft;
-              v[9] = cg == K::CG - 1 ? edge : rgt;
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) o[j] += w[dr * 3 + kx] * v[j + kx];
-            }
-            u32x4 oa, ob;                               // channel p (half 0) and channel p + 8 (half 1), 8 pixels each
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              oa[k] = pack_bf2(o[2 * k][0], o[2 * k + 1][0]);
-              ob[k] = pack_bf2(o[2 * k][1], o[2 * k + 1][1]);
-            }
-            if (kind == 2) {
-              bf16* vp = a.v + ((int64_t)b * C + 16 * blk + p) * HW + (int64_t)(y0 + row) * a.W + x0 + 8 * cg;
-              *reinterpret_cast<u32x4*>(vp) = oa;
-              *reinterpret_cast<u32x4*>(vp + 8 * HW) = ob;
-            } else {
-              unsigned char* fr = img + row * K::FRAG + cg * 256;
-              *reinterpret_cast<u32x4*>(fr + fm_slot(p, row, cg) * 16) = oa;
-              *reinterpret_cast<u32x4*>(fr + fm_slot(p + 8, row, cg) * 16) = ob;
-            }
-          }
-        }
-#pragma unroll
-        for (int n = 0; n < W1N; ++n) { const int vv = tt + NT * n; if (more && vv < W1V) reinterpret_cast<u32x4*>(W1)[vv] = wr1[n]; }
-        if (more && tt < WDV) reinterpret_cast<u32x4*>(WD + ((ci + 1) & 1) * (K::PC * 20))[tt] = wrd;
-      }
-      __syncthreads();
-      if ((a.dbg & 15) == 2 && ci == (a.dbg >> 8)) {      // debug: image of chunk (dbg >> 8) as [16][TH*32] bf16 into v of tile 0
-        if (blockIdx.x == 0 && tile == t0) {
-          const unsigned char* img = ci < K::NB ? KT + ci * (TH * K::FRAG) : QC;
-          for (int e = tt; e < 16 * TH * 32; e += NT) {
-            const int r = e / (TH * 32), px = e % (TH * 32), trow = px / 32, oct = (px % 32) / 8, w8 = px % 8;
-            a.v[e] = reinterpret_cast<const bf16*>(img + trow * K::FRAG + (oct * 16 + fm_slot(r, trow, oct)) * 16)[w8];
-          }
-        }
-        return;
-      }
-
-      // ------------------------------------------------------------ Gram: acc[rb][.] += Q_rb . K_cb^T over the tile's pixels
-      if (ci >= K::NB && ci < 2 * K::NB && !(a.dbg & 128)) {
-        const int rb = ci - K::NB;
+      // ------------------------------------------------------------ Gram of the PREVIOUS chunk if it was a q chunk
+      if (ci > K::NB && ci <= 2 * K::NB && !(a.dbg & 128)) {
+        const int rb = ci - 1 - K::NB;
+        const unsigned char* const Qp = QC + ((ci - 1) & 1) * K::QC_BYTES;
 #define FM_GRAM(RB)                                                                                              \
         case RB: {                                                                                               \
           if constexpr (RB < K::NB) {                                                                            \
             constexpr int head = RB / K::CB;                                                                     \
             constexpr bool first = (RB % K::CB) == 0;                                                            \
-            const bool qdiag = wv == (NW - 1 - RB % NW);                                                         \
-            _Pragma("unroll")                                                                                    \
-            for (int ks = 0; ks < TH; ++ks) {                                                                    \
-              const s16x8 af = fm_ldfrag(QC, ks, lane);                                                          \
+            if (wv < K::CB) {                                                                                    \
+              const unsigned char* const Kp = KT + (head * K::CB + wv) * (TH * K::FRAG);                         \
               _Pragma("unroll")                                                                                  \
-              for (int sl = 0; sl < K::NCBW; ++sl) {                                                             \
-                const int cb = wv + NW * sl;                                                                     \
-                if (cb < K::CB) {                                                                                \
-                  const s16x8 bf_ = fm_ldfrag(KT + (head * K::CB + cb) * (TH * K::FRAG), ks, lane);             \
-                  acc[RB][sl] = mfma32(af, bf_, acc[RB][sl]);                                                    \
-                  if (first) kd[head][sl] = mfma32(bf_, bf_, kd[head][sl]);                                      \
-                }                                                                                                \
+              for (int ks = 0; ks < TH; ++ks) {                                                                  \
+                const s16x8 af = fm_ldfrag(Qp, ks, lane);                                                        \
+                const s16x8 bf_ = fm_ldfrag(Kp, ks, lane);                                                       \
+                acc[RB] = mfma32(af, bf_, acc[RB]);                                                              \
+                if (first) kd[head] = mfma32(bf_, bf_, kd[head]);                                                \
               }                                                                                                  \
-              if (qdiag) qd[RB / NW] = mfma32(af, af, qd[RB / NW]);                                              \
+            } else if (wv == NW - 2 + (RB & 1)) {                                                                \
+              _Pragma("unroll")                                                                                  \
+              for (int ks = 0; ks < TH; ++ks) {                                                                  \
+                const s16x8 af = fm_ldfrag(Qp, ks, lane);                                                        \
+                qd[RB / 2] = mfma32(af, af, qd[RB / 2]);                                                         \
+              }                                                                                                  \
             }                                                                                                    \
           }                                                                                                      \
         } break;
@@ -479,6 +394,59 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
           default: break;
         }
 #undef FM_GRAM
+      }
+
+      // ------------------------------------------------------------ depthwise 3x3 (VALU): one (channel, tile row, octet) per lane
+      if (!(a.dbg & 64)) {
+        const int tt = wv * 64 + lane;
+        const int chrow = tt >> 5, row = (tt >> 2) & 7, cg = tt & 3;
+        const int kind = ci < K::NB ? 0 : (ci < 2 * K::NB ? 1 : 2);              // 0: k, 1: q, 2: v
+        const int blk = ci - kind * K::NB;
+        const float* wp = WD + (ci * K::CH + chrow) * 10;
+        float w[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) w[i] = wp[i];
+        const bf16* h = &H0c[chrow * K::PLANE];
+        const int eoff = K::BODY + (cg == 3 ? K::HR : 0);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = w[9];
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+          const int rin = row + dr;
+          const u32x4 r1 = *reinterpret_cast<const u32x4*>(h + rin * TW + 8 * cg);
+          const u16 e1 = reinterpret_cast<const u16*>(h)[eoff + rin];
+          float v[10];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[1 + 2 * k] = bf_lo(r1[k]); v[2 + 2 * k] = bf_hi(r1[k]); }
+          const float edge = bf_lo(e1), lft = from_prev_lane(v[8]), rgt = from_next_lane(v[1]);
+          v[0] = cg == 0 ? edge : lft;
+          v[9] = cg == 3 ? edge : rgt;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) o[j] += w[dr * 3 + kx] * v[j + kx];
+        }
+        u32x4 oa;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oa[k] = pack_bf2(o[2 * k], o[2 * k + 1]);
+        if (kind == 2) {
+          *reinterpret_cast<u32x4*>(a.v + ((int64_t)b * C + 16 * blk + chrow) * HW + (int64_t)(y0 + row) * a.W + x0 + 8 * cg) = oa;
+        } else {
+          unsigned char* img = kind == 0 ? KT + blk * (TH * K::FRAG) : QC + (ci & 1) * K::QC_BYTES;
+          *reinterpret_cast<u32x4*>(img + row * K::FRAG + cg * 256 + fm_slot(chrow, row, cg) * 16) = oa;
+        }
+      }
+      if ((a.dbg & 15) == 2 && ci == (a.dbg >> 8)) {      // debug: image of chunk (dbg >> 8) as [16][TH*32] bf16 into v of tile 0
+        __syncthreads();
+        if (blockIdx.x == 0 && tile == t0) {
+          const unsigned char* img = ci < K::NB ? KT + ci * (TH * K::FRAG) : QC + (ci & 1) * K::QC_BYTES;
+          for (int e = t; e < 16 * TH * 32; e += NT) {
+            const int r = e / (TH * 32), px = e % (TH * 32), trow = px / 32, oct = (px % 32) / 8, w8 = px % 8;
+            a.v[e] = reinterpret_cast<const bf16*>(img + trow * K::FRAG + (oct * 16 + fm_slot(r, trow, oct)) * 16)[w8];
+          }
+        }
+        return;
       }
     }
   }
@@ -490,30 +458,22 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
 #pragma unroll
     for (int rb = 0; rb < K::NB; ++rb) {
       const int head = rb / K::CB, ib = rb % K::CB;
+      if (wv < K::CB) {
 #pragma unroll
-      for (int sl = 0; sl < K::NCBW; ++sl) {
-        const int cb = wv + NW * sl;
-        if (cb < K::CB) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            pz[head * K::c * K::c + (ib * 16 + 4 * g + r) * K::c + cb * 16 + li] = acc[rb][sl][r];
-        }
+        for (int r = 0; r < 4; ++r)
+          pz[head * K::c * K::c + (ib * 16 + 4 * g + r) * K::c + wv * 16 + li] = acc[rb][r];
       }
-      if (wv == (NW - 1 - rb % NW) && (li >> 2) == g) {
-        const f32x4 d = qd[rb / NW];
+      if (wv == NW - 2 + (rb & 1) && (li >> 2) == g) {
+        const f32x4 d = qd[rb / 2];
         pz[HEADS * K::c * K::c + rb * 16 + li] = (li & 3) == 0 ? d[0] : ((li & 3) == 1 ? d[1] : ((li & 3) == 2 ? d[2] : d[3]));
       }
     }
 #pragma unroll
     for (int head = 0; head < HEADS; ++head)
-#pragma unroll
-      for (int sl = 0; sl < K::NCBW; ++sl) {
-        const int cb = wv + NW * sl;
-        if (cb < K::CB && (li >> 2) == g) {
-          const f32x4 d = kd[head][sl];
-          pz[HEADS * K::c * K::c + C + head * K::c + cb * 16 + li] =
-              (li & 3) == 0 ? d[0] : ((li & 3) == 1 ? d[1] : ((li & 3) == 2 ? d[2] : d[3]));
-        }
+      if (wv < K::CB && (li >> 2) == g) {
+        const f32x4 d = kd[head];
+        pz[HEADS * K::c * K::c + C + head * K::c + wv * 16 + li] =
+            (li & 3) == 0 ? d[0] : ((li & 3) == 1 ? d[1] : ((li & 3) == 2 ? d[2] : d[3]));
       }
   }
 }
@@ -548,9 +508,9 @@ static FmKind fm_kind(const mi_mdta_shape* s) {
 }
 static int fm_splits(const mi_mdta_shape* s, int TH) {
   const int tiles = (s->H / TH) * (s->W / 32);
-  int S = 512 / s->B;                                   // two 4-wave workgroups per CU
+  int S = 256 / s->B;                                   // one 8-wave workgroup per CU
   if (S < 1) S = 1;
-  if (S > 32) S = 32;
+  if (S > 256) S = 256;
   if (S > tiles) S = tiles;
   return S;
 }
@@ -657,9 +617,9 @@ extern "C" int mi_mdta_fused_fwd(const mi_mdta_shape* s, const mi_mdta_params* p
   const FmPackLayout l = fm_pack_layout(s->C);
   FmWs w = fm_ws_layout(s, ws);
   const int S = fm_splits(s, 8);
-  if (k == FM_48_1) MI_TRY((fm_launch<48, 1, 8, 4>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
-  else if (k == FM_96_2) MI_TRY((fm_launch<96, 2, 8, 4>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
-  else MI_TRY((fm_launch<96, 1, 8, 4>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
+  if (k == FM_48_1) MI_TRY((fm_launch<48, 1, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
+  else if (k == FM_96_2) MI_TRY((fm_launch<96, 2, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
+  else MI_TRY((fm_launch<96, 1, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
   {
     ProfScope ps(st, K_GRAM_REDUCE, 4.0 * s->B * (S + 1) * ((double)s->C * (s->C / s->heads) + 2.0 * s->C), 0.0);
     hipLaunchKernelGGL(fm_reduce_kernel, dim3(s->B * s->heads), dim3(256), 0, st, w.part, w.graw, w.ss, S, s->C, s->heads);

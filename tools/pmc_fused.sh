@@ -4,8 +4,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $OUT
-WHAT=fused
-run() { rocprofv3 --kernel-trace --pmc $2 -d $OUT -o ${WHAT}_$1 --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_fused.py gdfn > $OUT/${WHAT}_$1.log 2>&1; }
+MODE=${1:-gdfn}          # gdfn | mdta
+WHAT=fused_$MODE
+run() { rocprofv3 --kernel-trace --pmc $2 -d $OUT -o ${WHAT}_$1 --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_fused.py $MODE > $OUT/${WHAT}_$1.log 2>&1; }
 run a "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 run b "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"
 run c "SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS SQ_WAVE_CYCLES"
