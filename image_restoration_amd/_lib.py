@@ -110,6 +110,12 @@ SIGNATURES = {
     "mi_version": (C.c_int, []),
     "mi_last_error": (C.c_char_p, []),
     "mi_env_reload": (C.c_int, []),
+    "mi_deferred_begin": (C.c_int, [vp, C.c_size_t]),
+    "mi_deferred_record": (C.c_int, [C.c_int]),
+    "mi_deferred_pending": (C.c_int, []),
+    "mi_deferred_high_water": (C.c_size_t, []),
+    "mi_deferred_flush": (C.c_int, [vp]),
+    "mi_deferred_end": (C.c_int, []),
     "mi_ln_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "mi_ln_bwd_workspace": (C.c_size_t, [C.c_int, C.c_int, c_i64]),
     "mi_ln_bwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, fp, fp, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, C.c_int,

@@ -264,6 +264,19 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// ---- deferred parameter-gradient reductions (util.hip; C-ABI mi_deferred_*) ------------------------------------------------
+// Every weight gradient ends in a fixed-order sum of partial rows into the gradient buffer.  As separate launches those sums were
+// ~500 kernels of 5-15 us per training step.  While a caller-lent arena is active (mi_deferred_begin) a producer that ACCUMULATES
+// into its gradient buffer may put its partials into the arena (deferred_take) and record the sum as a job (deferred_reduce_rows)
+// instead of launching it; mi_deferred_flush runs all recorded jobs in ONE table-driven launch (a fixed order per job:
+// bitwise reproducible).  Nothing may read such a gradient before the flush - true for the trainer's main_grad buffers, which
+// are read by the all-reduce / optimizer only; producers whose caller reads the result at once (accumulate == 0) never defer.
+float* deferred_take(size_t nfloats);    // arena space for partials, or nullptr (inactive / arena or job table full)
+bool deferred_owns(const void* p);
+// true: recorded (part must come from deferred_take); false: not recorded, the caller launches the reduction itself
+bool deferred_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate, float scale,
+                          float* out2 = nullptr, int64_t split = 0);
+
 // generic small kernels implemented in util.hip, used by several modules
 constexpr int REDUCE_GROUPS = 32;
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld,

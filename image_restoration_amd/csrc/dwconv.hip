@@ -685,6 +685,10 @@ static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, co
   MI_CHECK_ARG(!dwg || (ws && x), "dwconv_bwd: weight gradient needs x and a workspace");
   int rc = MI_OK, rows = 0;
   float* part = (float*)ws;
+  if (dwg && accumulate) {   // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
+    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, Cc, H, W, ks) / sizeof(float));
+    if (arena) part = arena;
+  }
   if (gate) DW_DISPATCH(T, KS, (rc = dw_gate_bwd_launch<T, KS>(a, x, part, B, dwg != nullptr, &rows, st)));
   else DW_DISPATCH(T, KS, (rc = dw_bwd_launch<T, KS, IN_PLAIN>(a, x, part, B, dx != nullptr, dwg != nullptr, &rows, st)));
   if (rc != MI_OK) return rc;
@@ -717,6 +721,10 @@ extern "C" int mi_dwconv_gate_bwd_recompute(const void* dg, const void* x, const
   DwArgs a{dg, x, w, bias, dx, nullptr, C2, H, W, C2 / 2, 0};
   int rows = 0;
   float* part = (float*)ws;
+  if (dwg && accumulate) {
+    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, C2, H, W, ks) / sizeof(float));
+    if (arena) part = arena;
+  }
   {
     const double plane = (double)B * H * W * dtype_size(dtype);
     ProfScope ps(st, dx ? K_DW_GATE_BWD_DATA : K_DW_WGRAD, (C2 / 2 + (double)C2 + (dx ? C2 : 0)) * plane,

@@ -481,19 +481,25 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
 // graw[z][c*c] and ss[z][2c] (q sums of squares, then k) from the S partials of every image, summed in a fixed order
 __global__ __launch_bounds__(256) void fm_reduce_kernel(const float* __restrict__ part, float* __restrict__ graw, float* __restrict__ ss,
                                                         int S, int C, int heads) {
-  const int c = C / heads, z = blockIdx.x, b = z / heads, head = z - b * heads;
+  const int c = C / heads, z = blockIdx.y, b = z / heads, head = z - b * heads;
   const int64_t pstride = (int64_t)heads * c * c + 2 * C;
   const float* p0 = part + (int64_t)b * S * pstride;
-  for (int e = threadIdx.x; e < c * c + 2 * c; e += 256) {
-    int64_t off;
-    if (e < c * c) off = (int64_t)head * c * c + e;
-    else if (e < c * c + c) off = (int64_t)heads * c * c + head * c + (e - c * c);
-    else off = (int64_t)heads * c * c + C + head * c + (e - c * c - c);
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += p0[k * pstride + off];
-    if (e < c * c) graw[(int64_t)z * c * c + e] = s;
-    else ss[(int64_t)z * 2 * c + (e - c * c)] = s;
+  const int e = blockIdx.x * 256 + threadIdx.x;         // one output element per thread: the S partials in a fixed order
+  if (e >= c * c + 2 * c) return;
+  int64_t off;
+  if (e < c * c) off = (int64_t)head * c * c + e;
+  else if (e < c * c + c) off = (int64_t)heads * c * c + head * c + (e - c * c);
+  else off = (int64_t)heads * c * c + C + head * c + (e - c * c - c);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < S; k += 4) {
+    s0 += p0[(int64_t)k * pstride + off]; s1 += p0[(int64_t)(k + 1) * pstride + off];
+    s2 += p0[(int64_t)(k + 2) * pstride + off]; s3 += p0[(int64_t)(k + 3) * pstride + off];
   }
+  for (; k < S; ++k) s0 += p0[(int64_t)k * pstride + off];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (e < c * c) graw[(int64_t)z * c * c + e] = s;
+  else ss[(int64_t)z * 2 * c + (e - c * c)] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -511,7 +517,7 @@ static int fm_splits(const mi_mdta_shape* s, int TH) {
   int S = 256 / s->B;                                   // one 8-wave workgroup per CU
   if (S < 1) S = 1;
   if (S > 256) S = 256;
-  if (S > tiles) S = tiles;
+  if (S > tiles / 4) S = tiles / 4 > 0 ? tiles / 4 : 1;   // at least 4 tiles per workgroup: the resident weights and the partial amortise
   return S;
 }
 
@@ -622,7 +628,9 @@ extern "C" int mi_mdta_fused_fwd(const mi_mdta_shape* s, const mi_mdta_params* p
   else MI_TRY((fm_launch<96, 1, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
   {
     ProfScope ps(st, K_GRAM_REDUCE, 4.0 * s->B * (S + 1) * ((double)s->C * (s->C / s->heads) + 2.0 * s->C), 0.0);
-    hipLaunchKernelGGL(fm_reduce_kernel, dim3(s->B * s->heads), dim3(256), 0, st, w.part, w.graw, w.ss, S, s->C, s->heads);
+    const int cc = s->C / s->heads;
+    hipLaunchKernelGGL(fm_reduce_kernel, dim3(cdiv(cc * cc + 2 * cc, 256), s->B * s->heads), dim3(256), 0, st, w.part, w.graw, w.ss, S,
+                       s->C, s->heads);
     MI_LAUNCH_CHECK();
   }
   MI_TRY(launch_attn_fold(w.graw, w.ss, p->temperature, p->proj_w, w.P, w.A, w.nrm, w.M, s->B, s->C, s->heads, st));

@@ -422,6 +422,12 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
+// A weight-gradient Gram that accumulates into a dense [ma][mb] gradient may leave its split partials in the deferred arena
+// and have them summed by mi_deferred_flush (common.h): rows = splits x images of ma*mb floats, a plain fixed-order row sum.
+static bool gram_deferrable(const mi_gram_desc* d) {
+  return d->accumulate && d->sum_batch && d->groups == 1 && d->out_ld == d->mb && !d->sumsq;
+}
+
 struct GramPlan { int FA, FB, kc, nchunks, tiles_a, tiles_b, splits, cps, Z, fold; size_t part_bytes, ss_bytes; };
 
 // Weight gradients sum over the batch: instead of one partial tile per image (and a reduction over batch x splits partials),
@@ -559,6 +565,11 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   k.n = d->n; k.groups = d->groups; k.Z = g.Z; k.fold = g.fold;
   const bool direct = gram_direct(d, g.splits);
   k.part = direct ? d->out : (float*)ws;
+  bool deferred = false;
+  if (!direct && gram_deferrable(d)) {
+    float* arena = deferred_take(g.part_bytes / sizeof(float));
+    if (arena) { k.part = arena; deferred = true; }
+  }
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
   k.chunks_per_split = 0; k.nchunks = 0; k.tiles_b = g.tiles_b; k.vec_ok = 1;
   dim3 grid(g.splits, g.tiles_a * g.tiles_b, g.Z), block(256);
@@ -578,7 +589,10 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
 #undef GS_CASE
   }
   MI_LAUNCH_CHECK();
-  if (!direct) {
+  if (deferred) {
+    const int64_t per = (int64_t)d->ma * d->mb;
+    MI_TRY(launch_reduce_rows(k.part, d->out, (int64_t)g.splits * (g.fold ? 1 : d->batch), per, per, d->accumulate, 1.0f, st));
+  } else if (!direct) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;
@@ -614,6 +628,11 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   k.n = d->n; k.groups = d->groups; k.Z = g.Z; k.fold = g.fold;
   const bool direct = gram_direct(d, g.splits);
   k.part = direct ? d->out : (float*)ws;
+  bool deferred = false;
+  if (!direct && gram_deferrable(d)) {
+    float* arena = deferred_take(g.part_bytes / sizeof(float));
+    if (arena) { k.part = arena; deferred = true; }
+  }
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
   k.chunks_per_split = g.cps; k.nchunks = g.nchunks; k.tiles_b = g.tiles_b;
   const int64_t vec = d->dtype == MI_BF16 ? 8 : 4;
@@ -642,7 +661,10 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
 #undef GRAM_CASE
   }
   MI_LAUNCH_CHECK();
-  if (!direct) {
+  if (deferred) {
+    const int64_t per = (int64_t)d->ma * d->mb;
+    MI_TRY(launch_reduce_rows(k.part, d->out, (int64_t)g.splits * (g.fold ? 1 : d->batch), per, per, d->accumulate, 1.0f, st));
+  } else if (!direct) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;

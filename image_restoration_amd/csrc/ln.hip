@@ -592,6 +592,10 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
   MI_CHECK_ARG(dtype == MI_F32 || dtype == MI_BF16, "ln_bwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
+  if (accumulate) {          // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
+    float* arena = deferred_take(mi_ln_bwd_workspace(B, C, N) / sizeof(float));
+    if (arena) part = arena;
+  }
   int rows = 0, rc;
   if (dtype == MI_F32) {
     rc = with_bias ? ln_bwd_dispatch<float, true>((const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres,

@@ -193,10 +193,17 @@ static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, 
   if (g_proj_b) MI_TRY(launch_chan_sum(dout, g_proj_b, B, C, d.N, d.dtype, acc, w.cs_ws, st));
   mi_gram_desc g1 = attn_dm_gram(d, dout, v, w.dM);  // dM_b = dY V^T
   MI_TRY(mi_gram(&g1, w.gram_ws, stream));
-  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, w.dwo_part, w.dtemp_part, w.wd,
+  float* dwo_part = w.dwo_part;
+  float* dtemp_part = w.dtemp_part;
+  if (acc) {                 // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
+    float* a1 = deferred_take((size_t)B * C * C);
+    float* a2 = a1 ? deferred_take((size_t)B * hd) : nullptr;
+    if (a1 && a2) { dwo_part = a1; dtemp_part = a2; }
+  }
+  MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, dwo_part, dtemp_part, w.wd,
                                w.attn_scr, B, C, hd, st));
-  MI_TRY(launch_reduce_rows(w.dwo_part, g_proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
-  MI_TRY(launch_reduce_rows(w.dtemp_part, g_temperature, B, hd, hd, acc, 1.0f, st));
+  MI_TRY(launch_reduce_rows(dwo_part, g_proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
+  MI_TRY(launch_reduce_rows(dtemp_part, g_temperature, B, hd, hd, acc, 1.0f, st));
   // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
   // both in one pass over q and k where the GEMM form can write two outputs (bf16 wave-owned forms), else one GEMM each
   const int c = C / hd;

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate,
                        float scale, hipStream_t st, float* tmp, float* out2, int64_t split) {
   if (cols <= 0) return MI_OK;
+  // partials a producer placed in the deferred arena: record the sum, mi_deferred_flush runs it (common.h)
+  if (deferred_reduce_rows(part, out, rows, cols, part_ld, accumulate, scale, out2, split)) return MI_OK;
   if (tmp && rows > 4 * REDUCE_GROUPS) {
     const int64_t rpg = (rows + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
     {
@@ -122,6 +124,85 @@ int launch_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols
                      accumulate, scale, rows, (int64_t)0, out2, split);
   MI_LAUNCH_CHECK();
   return MI_OK;
+}
+
+// ---------------------------------------------------------------- deferred parameter-gradient reductions (common.h)
+struct DrJob {
+  const float* part; float* tmp; float* out; float* out2;
+  int64_t rows, cols, ld, split, rpg;
+  int groups, accumulate; float scale;
+  int blk1, blk2;                 // first workgroup of this job in stage 1 / stage 2
+};
+constexpr int DR_MAX_JOBS = 2048;
+constexpr size_t DR_TABLE_BYTES = DR_MAX_JOBS * sizeof(DrJob);
+static struct {
+  std::mutex mu;
+  bool active = false;
+  bool recording = false;         // producers defer only while the owner says so (mi_deferred_record): its backward window
+  char* arena = nullptr;
+  size_t bytes = 0, off = 0;
+  std::vector<DrJob> jobs;
+  DrJob* host_tab[2] = {nullptr, nullptr};   // pinned staging for the job table, used alternately
+  hipEvent_t copied[2] = {nullptr, nullptr}; // recorded behind each staging buffer's copy: waited for before its reuse
+  int flip = 0;
+  int nblk1 = 0, nblk2 = 0;
+  size_t high = 0;                // high-water mark of the arena (diagnostics: mi_deferred_high_water)
+} g_dr;
+
+float* deferred_take(size_t nfloats) {
+  std::lock_guard<std::mutex> lk(g_dr.mu);
+  if (!g_dr.active || !g_dr.recording || g_dr.jobs.size() + 1 >= (size_t)DR_MAX_JOBS) return nullptr;
+  const size_t need = align_up(nfloats * sizeof(float), 256);
+  if (g_dr.off + need > g_dr.bytes) return nullptr;
+  float* p = reinterpret_cast<float*>(g_dr.arena + g_dr.off);
+  g_dr.off += need;
+  if (g_dr.off > g_dr.high) g_dr.high = g_dr.off;
+  return p;
+}
+bool deferred_owns(const void* p) {
+  std::lock_guard<std::mutex> lk(g_dr.mu);
+  return g_dr.active && (const char*)p >= g_dr.arena + DR_TABLE_BYTES && (const char*)p < g_dr.arena + g_dr.bytes;
+}
+bool deferred_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate, float scale,
+                          float* out2, int64_t split) {
+  if (cols <= 0 || rows <= 0) return false;
+  if (!deferred_owns(part)) return false;
+  DrJob j;
+  j.part = part; j.out = out; j.out2 = out2; j.rows = rows; j.cols = cols; j.ld = part_ld; j.split = split;
+  j.accumulate = accumulate; j.scale = scale;
+  j.groups = 1; j.rpg = rows; j.tmp = nullptr;
+  std::lock_guard<std::mutex> lk(g_dr.mu);
+  if (!g_dr.active || g_dr.jobs.size() >= (size_t)DR_MAX_JOBS) return false;
+  j.blk1 = g_dr.nblk1; j.blk2 = 0;
+  g_dr.nblk1 += cdiv(cols, 256);
+  g_dr.jobs.push_back(j);
+  return true;
+}
+
+// One workgroup = 256 consecutive columns of one job, one column per thread, the rows walked in order with eight loads in
+// flight (eight partial sums combined in a fixed pattern: reproducible).  Coalesced 1-KiB row segments; the job is found by a
+// binary search over the jobs' first-workgroup indices.
+__global__ __launch_bounds__(256) void deferred_reduce_kernel(const DrJob* __restrict__ jobs, int njobs) {
+  const int bid = blockIdx.x;
+  int lo = 0, hi = njobs - 1;                            // the last job whose first workgroup is <= bid
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk1 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const DrJob j = jobs[lo];
+  const int64_t c = (int64_t)(bid - j.blk1) * 256 + threadIdx.x;
+  if (c >= j.cols) return;
+  const float* p = j.part + c;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int64_t r = 0;
+  for (; r + 7 < j.rows; r += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += p[(r + u) * j.ld];
+  }
+  for (; r < j.rows; ++r) a[0] += p[r * j.ld];
+  const float t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  float* o = (j.out2 && c >= j.split) ? j.out2 + (c - j.split) : j.out + c;
+  *o = (j.accumulate ? *o : 0.f) + j.scale * t;
 }
 
 // AdamW, torch semantics (decoupled weight decay, bias-corrected moments).
@@ -238,6 +319,64 @@ extern "C" int mi_prof_collect(double* ms, double* bytes, double* flops, int64_t
   return MI_OK;
 }
 extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" int mi_deferred_begin(void* arena, size_t bytes) {
+  MI_CHECK_ARG(arena && aligned16(arena) && bytes >= mi::DR_TABLE_BYTES + (1u << 20), "deferred_begin: arena too small (job table + 1 MiB)");
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  MI_CHECK_ARG(!mi::g_dr.active, "deferred_begin: already active (one deferral context per process)");
+  for (int i = 0; i < 2; ++i)
+    if (!mi::g_dr.host_tab[i]) {
+      MI_CHECK_HIP(hipHostMalloc((void**)&mi::g_dr.host_tab[i], mi::DR_TABLE_BYTES, hipHostMallocDefault));
+      MI_CHECK_HIP(hipEventCreateWithFlags(&mi::g_dr.copied[i], hipEventDisableTiming));
+      MI_CHECK_HIP(hipEventRecord(mi::g_dr.copied[i], nullptr));
+    }
+  mi::g_dr.arena = (char*)arena; mi::g_dr.bytes = bytes; mi::g_dr.off = mi::DR_TABLE_BYTES;
+  mi::g_dr.jobs.clear(); mi::g_dr.nblk1 = mi::g_dr.nblk2 = 0;
+  mi::g_dr.active = true;
+  mi::g_dr.recording = false;
+  return MI_OK;
+}
+extern "C" int mi_deferred_record(int on) {
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  MI_CHECK_ARG(mi::g_dr.active || !on, "deferred_record: no context (mi_deferred_begin)");
+  mi::g_dr.recording = on != 0;
+  return MI_OK;
+}
+extern "C" size_t mi_deferred_high_water(void) {
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  return mi::g_dr.high;
+}
+extern "C" int mi_deferred_pending(void) {
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  return mi::g_dr.active ? (int)mi::g_dr.jobs.size() : 0;
+}
+extern "C" int mi_deferred_flush(void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  if (!mi::g_dr.active || mi::g_dr.jobs.empty()) { if (mi::g_dr.active) mi::g_dr.off = mi::DR_TABLE_BYTES; return MI_OK; }
+  const int n = (int)mi::g_dr.jobs.size();
+  // two pinned staging tables used alternately: the one taken now was last copied from two flushes ago
+  const int f = mi::g_dr.flip;
+  mi::g_dr.flip ^= 1;
+  MI_CHECK_HIP(hipEventSynchronize(mi::g_dr.copied[f]));
+  memcpy(mi::g_dr.host_tab[f], mi::g_dr.jobs.data(), (size_t)n * sizeof(mi::DrJob));
+  MI_CHECK_HIP(hipMemcpyAsync(mi::g_dr.arena, mi::g_dr.host_tab[f], (size_t)n * sizeof(mi::DrJob), hipMemcpyHostToDevice, st));
+  MI_CHECK_HIP(hipEventRecord(mi::g_dr.copied[f], st));
+  double bytes = 0;
+  for (const auto& j : mi::g_dr.jobs) bytes += 4.0 * (double)(j.rows + 1) * j.cols;
+  {
+    ProfScope ps(st, K_REDUCE_ROWS, bytes, bytes / 4.0);
+    hipLaunchKernelGGL(mi::deferred_reduce_kernel, dim3(mi::g_dr.nblk1), dim3(256), 0, st, (const mi::DrJob*)mi::g_dr.arena, n);
+    MI_LAUNCH_CHECK();
+  }
+  mi::g_dr.jobs.clear(); mi::g_dr.nblk1 = mi::g_dr.nblk2 = 0; mi::g_dr.off = mi::DR_TABLE_BYTES;
+  return MI_OK;
+}
+extern "C" int mi_deferred_end(void) {
+  std::lock_guard<std::mutex> lk(mi::g_dr.mu);
+  MI_CHECK_ARG(mi::g_dr.jobs.empty(), "deferred_end: %d reductions still pending (call mi_deferred_flush first)", (int)mi::g_dr.jobs.size());
+  mi::g_dr.active = false; mi::g_dr.recording = false; mi::g_dr.arena = nullptr; mi::g_dr.bytes = mi::g_dr.off = 0;
+  return MI_OK;
+}
 extern "C" int mi_env_reload(void) {
   std::call_once(mi::g_env_once, mi::env_load);
   mi::env_load();

@@ -945,6 +945,49 @@ def pw_cache_invalidate() -> None:
     L.check(L.lib().mi_pw_cache_invalidate(), "pw_cache_invalidate")
 
 
+_deferred_arena: Optional[Tensor] = None
+
+
+def deferred_begin(nbytes: int, device) -> Optional[Tensor]:
+    """Lend the library an arena for deferred parameter-gradient reductions (include/mi_restore.h: mi_deferred_*): backward
+    calls that accumulate into gradient buffers record their final sums instead of launching them; deferred_flush() runs them
+    all in one launch.  Returns the owner token (the arena), or None when another owner already holds the context."""
+    global _deferred_arena
+    if _deferred_arena is not None:
+        return None
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    L.check(L.lib().mi_deferred_begin(buf.data_ptr(), buf.numel()), "deferred_begin")
+    _deferred_arena = buf
+    return buf
+
+
+def deferred_record(on: bool) -> None:
+    """Producers defer only while recording is on: the owner brackets its backward window with it."""
+    if _deferred_arena is not None:
+        L.check(L.lib().mi_deferred_record(int(on)), "deferred_record")
+
+
+def deferred_flush() -> None:
+    if _deferred_arena is not None:
+        L.check(L.lib().mi_deferred_flush(_stream()), "deferred_flush")
+
+
+def deferred_pending() -> int:
+    return int(L.lib().mi_deferred_pending()) if _deferred_arena is not None else 0
+
+
+def deferred_end(token: Optional[Tensor]) -> bool:
+    """Flush and close the deferral context if `token` owns it."""
+    global _deferred_arena
+    if token is None or _deferred_arena is not token:
+        return False
+    deferred_flush()
+    deferred_record(False)
+    L.check(L.lib().mi_deferred_end(), "deferred_end")
+    _deferred_arena = None
+    return True
+
+
 def prof_enable(on: bool) -> None:
     L.check(L.lib().mi_prof_enable(int(on)), "prof_enable")
 

@@ -118,6 +118,12 @@ class FlatTrainer:
         # The trainer is the only writer of the parameters, so it can let the library keep the packed (bf16, LDS-image)
         # copies of all 1x1 weights across calls and refresh them once per optimizer step (mi_pw_cache_*): 4 bytes of
         # cache per parameter covers both orientations of every matrix in either activation dtype, plus tile padding.
+        # Every weight gradient ends in a fixed-order sum of partial rows; with an arena lent to the library those ~500 small
+        # launches per step are recorded during backward and run as one table-driven launch before the gradients are used
+        # (reduce_gradients / each bucket's all-reduce).  MI_DEFER_MB sizes the arena (0 disables; overflow falls back to
+        # immediate sums).
+        defer_mb = int(ops.env("MI_DEFER_MB") or 3072)
+        self._defer_token = ops.deferred_begin(defer_mb << 20, dev) if (dev.type == "cuda" and defer_mb > 0) else None
         self._pack_cache = bool(pack_cache) and dev.type == "cuda"
         self._sync = True            # False inside no_sync(): micro-batches accumulate locally, nothing is reduced
         self._seen_fwd: set = set()
@@ -154,9 +160,17 @@ class FlatTrainer:
         if self._pack_cache and self._weights_version() != self._p_version:
             self.weights_changed()
 
+    def flush_deferred(self) -> None:
+        """Run the parameter-gradient sums recorded since the last flush (no-op without a deferral context)."""
+        if self._defer_token is not None:
+            ops.deferred_flush()
+
     def close(self) -> None:
         """Detach the library's packed-weight cache from this trainer's buffers.  The cache is process-global: it is switched
         off only if it still belongs to this trainer (a trainer or PackedWeights made later keeps its own)."""
+        if getattr(self, "_defer_token", None) is not None:
+            ops.deferred_end(self._defer_token)
+            self._defer_token = None
         if self._pack_cache:
             ops.pw_cache_release(getattr(self, "_cache_token", None))
             self._cache_token = None
@@ -204,6 +218,9 @@ class FlatTrainer:
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self) -> None:
+        if self._defer_token is not None:
+            ops.deferred_flush()              # (nothing should be pending; a stale job must not land in the zeroed buffer)
+            ops.deferred_record(True)         # this step's backward may defer its parameter-gradient sums
         self.flat_g.zero_()
         self._exec_order.clear()
         self._reduced.clear()
@@ -273,6 +290,7 @@ class FlatTrainer:
             return
         self._reduced.add(idx)
         _, child, lo, hi = self.stages[idx]
+        self.flush_deferred()           # the bucket's gradients must be final before they go out
         self._fold_autograd_grads(child)
         buf = self.flat_g[lo:hi]
         if self._comm_stream is not None:
@@ -284,6 +302,9 @@ class FlatTrainer:
 
     def reduce_gradients(self) -> None:
         """Call after backward: folds autograd-delivered grads, all-reduces whatever is not yet in flight, waits."""
+        self.flush_deferred()
+        if self._defer_token is not None:
+            ops.deferred_record(False)
         if not self._comm:
             self._fold_autograd_grads(self.model)
             return

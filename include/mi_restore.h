@@ -49,6 +49,22 @@ const char* mi_last_error(void);
  * them: for tests and A/B tools that flip a switch inside one process.  Not meant to race with launches on other threads. */
 int mi_env_reload(void);
 
+/* Deferred parameter-gradient reductions.  Every weight gradient of the blocks ends in a fixed-order sum of partial rows into
+ * the gradient buffer; as separate launches that was ~500 kernels of 5-15 us per training step.  Between mi_deferred_begin and
+ * mi_deferred_end, backward entry points called with accumulate != 0 place those partials in the lent arena (device memory,
+ * caller-owned, >= 2 MiB; a few GiB for a Restormer-base step - when it is full the entry points fall back to immediate sums)
+ * and record the sum instead of launching it; mi_deferred_flush(stream) runs everything recorded so far in one table-driven
+ * launch on `stream` (the stream the backward ran on), in a fixed order per gradient (bitwise reproducible), and
+ * recycles the arena.  Contract: nothing reads such a gradient buffer between the backward call and the flush (the trainer
+ * switches recording on in zero_grad() and flushes + switches it off before its all-reduce / optimizer step).  One context per
+ * process. */
+int mi_deferred_begin(void* arena, size_t bytes);
+int mi_deferred_record(int on);         /* producers defer only while recording is on (the owner's backward window); begin() leaves it off */
+int mi_deferred_pending(void);          /* reductions recorded and not yet flushed */
+size_t mi_deferred_high_water(void);    /* most arena bytes in use at once since the library was loaded (sizing aid) */
+int mi_deferred_flush(void* stream);
+int mi_deferred_end(void);
+
 /* ------------------------------------------------------------------------
  * Channel LayerNorm on NCHW  (Restormer.py:25-70; moce_ir.py:156-221;
  * AdaIR-main/net/model.py:25-71).  with_bias=1: (x-mu)/sqrt(var+1e-5)*w+b ;

@@ -290,3 +290,54 @@ def test_custom_op_route_equals_autograd_function_route(monkeypatch, dtype, bias
         assert len(a) == len(b)
         for u, v in zip(a, b):
             assert torch.equal(u, v)
+
+
+def test_deferred_gradient_reductions_match_the_immediate_ones(monkeypatch):
+    """The trainer lends the library an arena: backward calls that accumulate into the flat gradient buffer record their final
+    fixed-order sums and mi_deferred_flush runs them in one launch.  Same partials, a fixed order per gradient: two deferred runs
+    are bit-identical, and equal to a run with the deferral off (MI_DEFER_MB=0) up to fp32 summation order; the flat gradient is final after
+    reduce_gradients(), nothing stays pending, and a backward outside the trainer's window is not deferred."""
+    m = M()
+    from image_restoration_amd import ops
+    from image_restoration_amd.configs import RESTORMER_TINY
+    from image_restoration_amd.trainer import FlatTrainer
+    x = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(5)).to(DEV).to(torch.bfloat16)
+
+    def run(defer_mb):
+        monkeypatch.setenv("MI_DEFER_MB", str(defer_mb))
+        torch.manual_seed(3)
+        net = m.Restormer(**RESTORMER_TINY).to(DEV)
+        tr = FlatTrainer(net, lr=1e-2)
+        try:
+            assert (tr._defer_token is not None) == (defer_mb > 0)
+            grads = []
+            for _ in range(2):
+                tr.zero_grad()
+                net(x).float().abs().mean().backward()
+                if defer_mb > 0:
+                    assert ops.deferred_pending() > 0          # sums were recorded, not launched
+                tr.reduce_gradients()
+                assert ops.deferred_pending() == 0
+                grads.append(tr.flat_g.clone())
+                tr.optimizer_step()
+            return tr.flat_p.clone(), grads
+        finally:
+            tr.close()
+    p1, g1 = run(64)
+    p2, g2 = run(64)
+    p0, g0 = run(0)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1]) and torch.equal(p1, p2)     # fixed summation order: reproducible
+    # the first step's gradients: same partials as the immediate sums, another grouping of the fp32 additions.  (Later steps
+    # cannot be compared this tightly: after an AdamW step on gradients that differ in the last bit, bf16 rounding flips inside
+    # the network move individual gradient elements by 1e-3.)
+    assert rel(g1[0], g0[0]) < 1e-5, rel(g1[0], g0[0])
+    assert rel(p1, p0) < 1e-2
+    # outside a trainer's window nothing is deferred: main_grad accumulation is visible right after backward
+    blk = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
+    tr = FlatTrainer(blk, lr=1e-2)
+    try:
+        xb = seeded_input((1, 48, 16, 64), 7).to(DEV).to(torch.bfloat16)
+        blk(xb).float().sum().backward()                       # no zero_grad() before: recording is off
+        assert ops.deferred_pending() == 0 and float(tr.flat_g.abs().sum()) > 0
+    finally:
+        tr.close()
