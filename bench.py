@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                      fusion, 3 x 4 C N s bytes per block): this is the number fusion moves, the per-kernel one is not;
   mdta_contraction : the MDTA contraction (q k^T and attn v of every block, forward) by itself: flops, ms, MFMA and HBM
                      fractions - the north_star's 40 % MFMA target is quoted against this;
+  inference_forward: the no_grad forward of the same model and batch, with the fused MDTA pass A kernel's own MFMA / HBM fractions
+                     (q, k and qkv0 never reach HBM on that path);
   fp32_line        : a short run of the same step with fp32 activations (the exact-MFMA parity path, the reference's
                      mainline precision), reported beside the bf16 headline, never instead of it;
   cpu_baseline     : the CPU oracle (oracle/restormer_ref.py, "port") timed on this box's host cores: warm-up + median of
@@ -358,6 +360,37 @@ def main():
             with open(args.profile_json, "w") as f:
                 json.dump({"steps_profiled": nprof, "kernels": rows}, f, indent=1)
 
+    infer = None
+    if world == 1 and rank == 0 and args.model == "restormer" and args.dtype == "bf16" and not args.no_roofline:
+        # the no_grad forward of the same model and batch: the path whose MDTA contraction is fused (pass A: LN -> qkv -> dw3x3 ->
+        # q k^T partials + v in one launch, csrc/fused_mdta.hip) - q, k and qkv0 never reach HBM there
+        model.eval()
+        with torch.no_grad():
+            model(noisy)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model(noisy)
+            torch.cuda.synchronize()
+            dt_inf = (time.perf_counter() - t1) / 3
+            ops.prof_enable(True)
+            model(noisy)
+            torch.cuda.synchronize()
+            tab = ops.prof_collect()
+            ops.prof_enable(False)
+        model.train()
+        fa, av = tab.get("mdta_fused_a"), tab.get("mdta_av") or tab.get("pw_gemm")
+        infer = {"what": "no_grad forward, same model and batch (one-launch LN+GDFN half-blocks; MDTA pass A fused where C is 48 / 96)",
+                 "ms": round(dt_inf * 1e3, 3), "mpix_s": round(batch * patch * patch / dt_inf / 1e6, 3)}
+        if fa:
+            infer["mdta_pass_a_fused"] = {
+                "what": "LN -> qkv 1x1 -> dw3x3 -> q k^T partials + row norms + v, one launch per block (24 of 44 blocks); HBM: x in, v out",
+                "launches": fa["launches"], "ms": round(fa["ms"], 3), "tflops": round(fa["flops"] / fa["ms"] / 1e9, 1),
+                "mfma_frac": round(fa["flops"] / fa["ms"] / 1e9 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                "hbm_gbs": round(fa["bytes"] / fa["ms"] / 1e6, 1), "hbm_frac": round(fa["bytes"] / fa["ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                "target_mfma_frac": 0.40,
+                "note": "latency-bound at two waves per SIMD (profiles/r03_c_*): neither roof; see DESIGN.md section 7c"}
+
     fp32_line = None
     if world == 1 and rank == 0 and args.dtype == "bf16" and not args.no_fp32_line and not moce:
         # the parity path (exact fp32 MFMA, the reference's mainline precision) timed beside the headline: bs 8, 5 steps
@@ -405,7 +438,8 @@ def main():
             "config": {"workload": workload, "per_gpu_batch": batch, "global_batch": batch * world, "patch": patch,
                        "parallelism": f"dp{world}", "hip_graph": bool(graph is not None), "final_loss": final_loss,
                        "peak_hbm_gib": peak_gib},
-            "roofline": roofline, "step_roofline": step_roofline, "mdta_contraction": contraction, "fp32_line": fp32_line,
+            "roofline": roofline, "step_roofline": step_roofline, "mdta_contraction": contraction, "inference_forward": infer,
+            "fp32_line": fp32_line,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
