@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def parse():
@@ -115,8 +115,8 @@ def pmc_traffic(kernel: str):
 
 def cpu_baseline():
     """The CPU oracle's training step, fp32, on this box's host cores (SURVEY 8(d) / BASELINE.md s.3: 1 x 3 x 256^2).
-    A thread sweep on a 128^2 patch (forward at all cores / 16 / 8 threads, forward + backward at 16 / 8: oneDNN's small
-    convolutions do not scale to a whole socket) picks the thread count; the quoted value is forward + L1 + backward on ONE
+    A thread sweep on a 128^2 patch (16 / 8 threads: oneDNN's small convolutions do not scale to a whole socket - round 2
+    measured all 64 threads 5-10x slower) picks the thread count; the quoted value is forward + L1 + backward on ONE
     256 x 256 patch at that setting, warm-up + median of 3, with the forward-only rate beside it.  ~30 s in all."""
     from image_restoration_amd.configs import RESTORMER_BASE as cfg
     from oracle import restormer_ref as R
@@ -144,15 +144,12 @@ def cpu_baseline():
             fn(*args)
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
-    allc = min(os.cpu_count() or 1, 64)
     t_start = time.perf_counter()
     small = data(128)
     sweep = {}
-    for threads in sorted({allc, 16, 8}, reverse=True):
+    for threads in (16, 8):                             # (all 64 host threads is 5-10x slower than 16 on these small convolutions)
         torch.set_num_threads(threads)
-        sweep[threads] = {"fwd_s": med(fwd, small)}
-        if threads <= 16:
-            sweep[threads]["train_s"] = med(train, small)
+        sweep[threads] = {"fwd_s": med(fwd, small), "train_s": med(train, small)}
     best = min((t for t in sweep if "train_s" in sweep[t]), key=lambda t: sweep[t]["train_s"])
     torch.set_num_threads(best)
     big = data(256)

@@ -187,6 +187,15 @@ __device__ __forceinline__ void fm_stage_store(const FmStage<K>& st, bf16* S, in
   }
 }
 
+// Diagnostic build path (MI_FM_DEBUG & 0x1000): shader-clock stamps around the phases, summed per wave and written as floats to
+// the `mean` buffer ([workgroup][wave][8]: stage + barrier, LayerNorm, GEMM1, barrier wait, Gram, conv, whole kernel, tiles).
+// Stamps serialise what the real kernel overlaps: read the SHARES, never the run time of such a run.
+__device__ __forceinline__ unsigned long long fm_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+
 // One 8-wave workgroup per CU walks a contiguous range of one image's TH x 32 tiles.  Resident for its whole life: the packed
 // weights of all 3C output channels (LDS), its share of the Gram accumulators (registers).  Per tile, per 16-channel chunk:
 //   GEMM1(ci) -> H0[ci & 1]   |barrier|   Gram(ci - 1, if that was a q chunk)   conv(ci) -> K image / Q[ci & 1] / HBM
@@ -218,6 +227,9 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
 #pragma unroll
   for (int i = 0; i < K::NQD; ++i) qd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool stamp = (a.dbg & 0x1000) != 0;
+  unsigned long long tk0 = 0, ta = 0, tb = 0, c_stage = 0, c_ln = 0, c_gemm = 0, c_bar = 0, c_gram = 0, c_conv = 0;
+  if (stamp) tk0 = fm_clock();
   FmStage<K> stg;
   if (t0 < t1) fm_stage_load<K>(stg, xb, t, (t0 % a.tiles_x) * TW, (t0 / a.tiles_x) * TH, a.H, a.W, HW);
   {                                                       // the weights of every chunk: global -> LDS, once
@@ -230,9 +242,11 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
   for (int tile = t0; tile < t1; ++tile) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
+    if (stamp) ta = fm_clock();
     __syncthreads();                                      // every wave is done with the previous tile: the aliased region is free
     fm_stage_store<K>(stg, S, t);
     __syncthreads();
+    if (stamp) { tb = fm_clock(); c_stage += tb - ta; ta = tb; }
 
     // ---------------------------------------------------------------- LN(x) -> A-operand fragments (registers)
     // element order of a 32-k fragment (same for A and B): j < 4 is k = 4g + j, j >= 4 is k = 16 + 4g + (j - 4)
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
           if (K::KT16)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xt[i][j] = bf_bits(v[8 * K::KS32 + j]);
-          if (a.mean && g == 0) {                       // statistics of the tile's own pixels
+          if (a.mean && g == 0 && !(a.dbg & 0x1000)) {   // statistics of the tile's own pixels
             const int ipx = mt * 16 + li;
             if (ipx < K::BODY) {
               const int rr = ipx / TW, col = ipx % TW;
@@ -319,10 +333,13 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
         }
       }
     }
+    if (stamp) { tb = fm_clock(); c_ln += tb - ta; ta = tb; }
     __syncthreads();                                      // the staged x is dead: the region becomes the h0 buffers / the K image
+    if (stamp) { tb = fm_clock(); c_bar += tb - ta; }
 
 #pragma unroll 1
     for (int ci = 0; ci < K::NCHUNK; ++ci) {
+      if (stamp) ta = fm_clock();
       int lane_c = lane_outer;
       asm volatile("" : "+v"(lane_c));
       const int lane = lane_c, li = lane & 15, g = lane >> 4;
@@ -360,7 +377,9 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
           }
         }
       }
+      if (stamp) { tb = fm_clock(); c_gemm += tb - ta; ta = tb; }
       __syncthreads();
+      if (stamp) { tb = fm_clock(); c_bar += tb - ta; ta = tb; }
 
       // ------------------------------------------------------------ Gram of the PREVIOUS chunk if it was a q chunk
       if (ci > K::NB && ci <= 2 * K::NB && !(a.dbg & 128)) {
@@ -396,6 +415,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
 #undef FM_GRAM
       }
 
+      if (stamp) { tb = fm_clock(); c_gram += tb - ta; ta = tb; }
       // ------------------------------------------------------------ depthwise 3x3 (VALU): one (channel, tile row, octet) per lane
       if (!(a.dbg & 64)) {
         const int tt = wv * 64 + lane;
@@ -437,7 +457,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
           *reinterpret_cast<u32x4*>(img + row * K::FRAG + cg * 256 + fm_slot(chrow, row, cg) * 16) = oa;
         }
       }
-      if ((a.dbg & 15) == 2 && ci == (a.dbg >> 8)) {      // debug: image of chunk (dbg >> 8) as [16][TH*32] bf16 into v of tile 0
+      if (stamp) { tb = fm_clock(); c_conv += tb - ta; }
+      if ((a.dbg & 15) == 2 && ci == ((a.dbg >> 8) & 15)) { // debug: image of chunk (dbg >> 8) as [16][TH*32] bf16 into v of tile 0
         __syncthreads();
         if (blockIdx.x == 0 && tile == t0) {
           const unsigned char* img = ci < K::NB ? KT + ci * (TH * K::FRAG) : QC + (ci & 1) * K::QC_BYTES;
@@ -451,6 +472,11 @@ __global__ __launch_bounds__(64 * NW, 2) void fm_fwd_kernel(FmArgs a) {
     }
   }
 
+  if (stamp && a.mean && lane_outer == 0) {
+    float* o = a.mean + ((int64_t)blockIdx.x * NW + wv) * 8;
+    o[0] = (float)c_stage; o[1] = (float)c_ln; o[2] = (float)c_gemm; o[3] = (float)c_bar; o[4] = (float)c_gram; o[5] = (float)c_conv;
+    o[6] = (float)(fm_clock() - tk0); o[7] = (float)(t1 - t0);
+  }
   // ------------------------------------------------------------------ this workgroup's partial: G blocks, then sums of squares
   {
     const int lane = lane_outer, li = lane & 15, g = lane >> 4;
