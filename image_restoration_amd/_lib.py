@@ -199,6 +199,8 @@ SIGNATURES = {
     "mi_gdfn_fused_pack_bytes": (C.c_size_t, [C.POINTER(GdfnFusedShape)]),
     "mi_gdfn_fused_pack": (C.c_int, [C.POINTER(GdfnFusedShape), fp, fp, C.POINTER(GdfnParams), vp, vp]),
     "mi_gdfn_fused_fwd": (C.c_int, [C.POINTER(GdfnFusedShape), vp, vp, vp, fp, fp, vp]),
+    "mi_gdfn_fused_fwd_train_ok": (C.c_int, [C.POINTER(GdfnFusedShape)]),
+    "mi_gdfn_fused_fwd_train": (C.c_int, [C.POINTER(GdfnFusedShape), vp, vp, vp, fp, fp, vp, vp]),
     "mi_gdfn_fused_fwd_f8": (C.c_int, [C.POINTER(GdfnFusedShape), vp, C.POINTER(F8Scales), vp, vp, vp]),
     "mi_mdta_fused_ok": (C.c_int, [C.POINTER(MdtaShape)]),
     "mi_mdta_fused_pack_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),

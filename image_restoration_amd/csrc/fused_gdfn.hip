@@ -24,6 +24,9 @@
 
 namespace mi {
 using namespace fz;
+#ifndef FG_SAVE_PREFETCH
+#define FG_SAVE_PREFETCH 1
+#endif
 
 template <int C_, int TH_, int TW_, int PC_, int NW_> struct FgCfg {
   static constexpr int C = C_, TH = TH_, TW = TW_, PC = PC_, NW = NW_;
@@ -76,6 +79,7 @@ struct FgArgs {
   const bf16* w1p; const bf16* w2p; const float* wdp; const float* b2;
   int B, H, W, nch, with_bias, tiles_x, tiles_y, dbg, xcd_pairs;
   float f8_x1, f8_w1, f8_x2, f8_w2;    // fp8 operand form: scales of the normalised input, W_in', the gated hidden tensor, W_out
+  bf16* h0s; bf16* gs; int hidden;     // training form (SAVE): project_in output [B][2h][H][W] and gate output [B][h][H][W] for the backward
 };
 
 // packed-weight blob layout (bytes from its base), shared by the pack kernel and the launcher
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void fg_pack_kernel(FgPackArgs a) {
   }
 }
 
-template <int C, int TH, int TW, int PC, int NW, bool F8>
+template <int C, int TH, int TW, int PC, int NW, bool F8, bool SAVE = false>
 __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
   using K = FgCfg<C, TH, TW, PC, NW>;
   constexpr int NT = K::NT;
@@ -402,21 +406,40 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
       return;
     }
 
+    if constexpr (SAVE) {
+      // training form: the finished h0 chunk (tile rows only, no halo) goes to HBM for the backward's recompute of the conv
+      // (before the weight prefetch below claims its registers)
+      constexpr int SV = 2 * PC * TH * K::VPR;         // 16-byte vectors
+      static_assert(SV % NT == 0, "h0 rows split evenly over the threads");
+      bf16* const hb = a.h0s + (((int64_t)b * 2 * a.hidden + c * PC) * a.H + y0) * a.W + x0;      // wave-uniform base
+      const int hstep = a.hidden * a.H * a.W;
+#pragma unroll
+      for (int n = 0; n < SV / NT; ++n) {
+        const int v = t + NT * n;
+        const int row = v / (TH * K::VPR), rem = v - row * (TH * K::VPR), r = rem / K::VPR, u = rem - r * K::VPR;
+        const int half = row / PC, p = row - half * PC;
+        if (c * PC + p < a.hidden) {
+          const u32x4 hv = *reinterpret_cast<const u32x4*>(&H0[row * K::PLANE + (r + 1) * TW + 8 * u]);
+          *reinterpret_cast<u32x4*>(hb + (int64_t)half * hstep + (p * a.H + r) * a.W + 8 * u) = hv;
+        }
+      }
+    }
     // ------------------------------------------------------------ depthwise 3x3 + GELU gate, VALU; weights for the next GEMMs in flight
     {
       u32x4 wr1[W1N], wr2[W2N], wrd = {0u, 0u, 0u, 0u};
       const bool more = c + 1 < a.nch;
       const float* const wdc = WD + (c & 1) * (PC * 20);
-      {
+      const u32x4* const s1 = reinterpret_cast<const u32x4*>(a.w1p + (int64_t)(c + 1) * 2 * PC * K::W1S);
+      const u32x4* const s2 = reinterpret_cast<const u32x4*>(a.w2p + (int64_t)c * C * K::W2S);
+      if constexpr (!SAVE || FG_SAVE_PREFETCH) {
         if (more && t < WDV) wrd = reinterpret_cast<const u32x4*>(a.wdp + (int64_t)(c + 1) * PC * 20)[t];
-        const u32x4* s1 = reinterpret_cast<const u32x4*>(a.w1p + (int64_t)(c + 1) * 2 * PC * K::W1S);
-        const u32x4* s2 = reinterpret_cast<const u32x4*>(a.w2p + (int64_t)c * C * K::W2S);
 #pragma unroll
         for (int n = 0; n < W1N; ++n) { const int v = t + NT * n; if (more && v < W1V) wr1[n] = s1[v]; }
 #pragma unroll
         for (int n = 0; n < W2N; ++n) { const int v = t + NT * n; if (v < W2V) wr2[n] = s2[v]; }
       }
       const int cg = lane % K::CG, rl = (lane / K::CG) % K::ROWS, psel = lane / (K::CG * K::ROWS);
+      bf16* const gbase = SAVE ? a.gs + (((int64_t)b * a.hidden + c * PC) * a.H + y0) * a.W + x0 : nullptr;   // wave-uniform
 #pragma unroll 1
       for (int s = 0; s < ((a.dbg & 64) ? 0 : K::PPW / K::NPAIR); ++s) {
         const int p = wv * K::PPW + s * K::NPAIR + psel;
@@ -468,7 +491,18 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) gg[j] = gelu_erf(o[j][0]) * o[j][1];
           Vec<bf16, 8>::st(&G[p * K::GS + row * TW + 8 * cg], gg);
+          if constexpr (SAVE) {
+            if (c * PC + p < a.hidden)
+              Vec<bf16, 8>::st(gbase + (p * a.H + row) * a.W + 8 * cg, gg);
+          }
         }
+      }
+      if constexpr (SAVE && !FG_SAVE_PREFETCH) {
+        if (more && t < WDV) wrd = reinterpret_cast<const u32x4*>(a.wdp + (int64_t)(c + 1) * PC * 20)[t];
+#pragma unroll
+        for (int n = 0; n < W1N; ++n) { const int v = t + NT * n; if (more && v < W1V) wr1[n] = s1[v]; }
+#pragma unroll
+        for (int n = 0; n < W2N; ++n) { const int v = t + NT * n; if (v < W2V) wr2[n] = s2[v]; }
       }
 #pragma unroll
       for (int n = 0; n < W1N; ++n) { const int v = t + NT * n; if (more && v < W1V) reinterpret_cast<u32x4*>(W1)[v] = wr1[n]; }
@@ -599,9 +633,10 @@ static FgKind fg_kind(const mi_gdfn_fused_shape* s) {
   return FG_NONE;
 }
 
-template <int C, int TH, int TW, int PC, int NW, bool F8 = false>
+template <int C, int TH, int TW, int PC, int NW, bool F8 = false, bool SAVE = false>
 static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const void* pack, const void* y, void* out,
-                     float* mean, float* rstd, hipStream_t st, const mi_f8_scales* f8 = nullptr) {
+                     float* mean, float* rstd, hipStream_t st, const mi_f8_scales* f8 = nullptr, void* h0s = nullptr,
+                     void* gs = nullptr) {
   using K = FgCfg<C, TH, TW, PC, NW>;
   FgArgs a;
   const unsigned char* pk = (const unsigned char*)pack;
@@ -611,15 +646,16 @@ static int fg_launch(const mi_gdfn_fused_shape* s, const FgPackLayout& l, const 
   a.B = s->B; a.H = s->H; a.W = s->W; a.nch = l.nch; a.with_bias = s->ln_with_bias;
   a.tiles_x = s->W / TW; a.tiles_y = s->H / TH;
   a.f8_x1 = f8 ? f8->x1 : 1.f; a.f8_w1 = f8 ? f8->w1 : 1.f; a.f8_x2 = f8 ? f8->x2 : 1.f; a.f8_w2 = f8 ? f8->w2 : 1.f;
+  a.h0s = (bf16*)h0s; a.gs = (bf16*)gs; a.hidden = s->hidden;
   { const char* e = MI_ENV(MI_FG_DEBUG); a.dbg = e ? atoi(e) : 0; }
   const int64_t tiles = (int64_t)s->B * a.tiles_x * a.tiles_y;
   MI_CHECK_ARG(tiles < (1ll << 31), "gdfn_fused: grid too large");
   a.xcd_pairs = (TW == 32 && tiles % 16 == 0 && !MI_ENV(MI_FG_NOXCD)) ? 1 : 0;
-  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW, F8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  MI_CHECK_HIP(hipFuncSetAttribute((const void*)fg_fwd_kernel<C, TH, TW, PC, NW, F8, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES));
   const double N = (double)s->H * s->W * s->B, h = s->hidden;
-  ProfScope ps(st, K_GDFN_FUSED_FWD, 2.0 * C * N * 2.0, 2.0 * N * (3.0 * C * h) + 2.0 * N * 9.0 * 2.0 * h);
-  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, TW, PC, NW, F8>), dim3((unsigned)tiles), dim3(64 * NW), K::LDS_BYTES, st, a);
+  ProfScope ps(st, K_GDFN_FUSED_FWD, (2.0 * C + (SAVE ? 3.0 * h : 0.0)) * N * 2.0, 2.0 * N * (3.0 * C * h) + 2.0 * N * 9.0 * 2.0 * h);
+  hipLaunchKernelGGL((fg_fwd_kernel<C, TH, TW, PC, NW, F8, SAVE>), dim3((unsigned)tiles), dim3(64 * NW), K::LDS_BYTES, st, a);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -687,6 +723,34 @@ extern "C" int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack,
   set_error("gdfn_fused_fwd: no kernel for C=%d th=%d tw=%d pc=%d", s->C, f.th, f.tw, f.pc);
   return MI_ERR_ARG;
 }
+
+// Training form: the same launch also writes what the backward reads - the project_in output h0 [B][2h][H][W] (the depthwise
+// conv is recomputed from it) and the gate output g [B][h][H][W] (operand of project_out's weight gradient) - so the forward of
+// the half-block is one launch instead of GEMM -> depthwise gate -> GEMM: it reads y once and writes out, h0, g once
+// (10 C planes per pixel with h = 2.66 C against the chain's 19).  Default tile forms only.
+namespace mi {
+int fused_gdfn_fwd_save(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean, float* rstd,
+                        void* h0, void* g, hipStream_t st) {
+  const FgKind k = fg_kind(s);
+  MI_CHECK_ARG(k != FG_NONE, "gdfn_fused_fwd_train: shape not covered by the fused kernels (mi_gdfn_fused_ok)");
+  MI_CHECK_ARG(pack && y && out && mean && rstd && h0 && g, "gdfn_fused_fwd_train: null pointer");
+  MI_CHECK_ARG(aligned16(pack) && aligned16(y) && aligned16(out) && aligned16(h0) && aligned16(g),
+               "gdfn_fused_fwd_train: pointers must be 16-byte aligned");
+  const FgSel f = fg_select(s->C, s->H);
+  const FgPackLayout l = fg_pack_layout(s->C, s->hidden, f.pc);
+#define FGS_CASE(CC, TH, TW, PC, NW) \
+  if (s->C == CC && f.th == TH && f.tw == TW && f.pc == PC && f.nw == NW) \
+    return fg_launch<CC, TH, TW, PC, NW, false, true>(s, l, pack, y, out, mean, rstd, st, nullptr, h0, g)
+  FGS_CASE(48, 16, 32, 16, 4);
+  FGS_CASE(48, 8, 32, 16, 4);
+  FGS_CASE(96, 8, 32, 16, 4);
+  FGS_CASE(48, 16, 64, 16, 8);
+  FGS_CASE(96, 8, 64, 32, 8);
+#undef FGS_CASE
+  set_error("gdfn_fused_fwd_train: no saving kernel for C=%d th=%d tw=%d pc=%d", s->C, f.th, f.tw, f.pc);
+  return MI_ERR_ARG;
+}
+}  // namespace mi
 
 // The same launch with fp8 (e4m3) MFMA operands in both projections (inference; default tile forms only).  f8->x1 scales the
 // NORMALISED input ((y - mu) rstd, |.| <= sqrt(C)) and f8->w1 the packed W_in . diag(gamma); x2 / w2 as in mi_gdfn_fwd_f8.

@@ -50,4 +50,7 @@ size_t bwd_tail_workspace(int M, int C);
 int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
                     const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma, float* dbeta,
                     int B, int64_t N, int accumulate, void* ws, hipStream_t st);
+// ---- fused GDFN forward, training form (fused_gdfn.hip): also writes h0 [B][2h][H][W] and g [B][h][H][W] ----
+int fused_gdfn_fwd_save(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean, float* rstd,
+                        void* h0, void* g, hipStream_t st);
 }  // namespace mi

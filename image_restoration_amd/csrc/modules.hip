@@ -656,6 +656,23 @@ extern "C" int mi_gdfn_fwd_f8(const mi_gdfn_shape* s, const mi_gdfn_params* p, c
   return gdfn_fwd_impl(s, p, x, residual, out, nullptr, ws, stream, ln, f8);
 }
 
+// One-launch forward of the LayerNorm + GDFN half-block on the TRAINING path (csrc/fused_gdfn.hip): `saved` is the blob
+// mi_gdfn_saved_bytes sizes for this shape (flags 0: h0 and g; the conv output is recomputed in backward), so mi_gdfn_bwd /
+// mi_gdfn_bwd_ln read it exactly as after mi_gdfn_fwd_ln.
+extern "C" int mi_gdfn_fused_fwd_train_ok(const mi_gdfn_fused_shape* f) {
+  if (!f || !mi_gdfn_fused_ok(f)) return 0;
+  mi_gdfn_shape s = {f->B, f->C, f->hidden, f->H, f->W, MI_BF16, 3, 0};
+  return gdfn_check(&s) == MI_OK && gdfn_recompute(&s) ? 1 : 0;
+}
+extern "C" int mi_gdfn_fused_fwd_train(const mi_gdfn_fused_shape* f, const void* pack, const void* y, void* out, float* mean,
+                                       float* rstd, void* saved, void* stream) {
+  MI_CHECK_ARG(mi_gdfn_fused_fwd_train_ok(f), "gdfn_fused_fwd_train: shape not covered (mi_gdfn_fused_fwd_train_ok)");
+  MI_CHECK_ARG(saved, "gdfn_fused_fwd_train: null saved blob");
+  mi_gdfn_shape s = {f->B, f->C, f->hidden, f->H, f->W, MI_BF16, 3, 0};
+  GdfnSaved sv = gdfn_saved_layout(&s, saved);
+  return fused_gdfn_fwd_save(f, pack, y, out, mean, rstd, sv.h0, sv.g, (hipStream_t)stream);
+}
+
 static int gdfn_bwd_impl(const mi_gdfn_shape* s, const mi_gdfn_params* p, const void* x, const void* dout, void* dx,
                          const mi_gdfn_grads* gr, const void* saved, void* ws, void* stream, const mi_ln_tail* ln) {
   MI_TRY(gdfn_check(s));

@@ -588,6 +588,28 @@ def gdfn_fused_fwd(y: Tensor, pack: Tensor, hidden: int, with_bias: bool, want_s
     return out, mean, rstd
 
 
+def gdfn_fused_train_ok(x: Tensor, hidden: int, ks: int = 3) -> bool:
+    """True when the one-launch LN + GDFN forward can also write what the backward reads (mi_gdfn_fused_fwd_train)."""
+    if x.dtype != torch.bfloat16 or ks != 3 or not x.is_cuda:
+        return False
+    return bool(L.lib().mi_gdfn_fused_fwd_train_ok(C.byref(_gdfn_fused_shape(x, hidden, True))))
+
+
+def gdfn_fused_fwd_train(y: Tensor, pack: Tensor, hidden: int, with_bias: bool):
+    """out = y + GDFN(LN(y)) in one launch on the TRAINING path -> (out, saved, mean, rstd): ``saved`` is the blob gdfn_bwd
+    reads (project_in output + gate output), mean / rstd the LayerNorm statistics of y."""
+    _gpu(y, pack)
+    s = _gdfn_fused_shape(y, hidden, with_bias)
+    lib = L.lib()
+    out = torch.empty_like(y)
+    mean = torch.empty((y.shape[0], y.shape[2] * y.shape[3]), dtype=torch.float32, device=y.device)
+    rstd = torch.empty_like(mean)
+    saved = _blob(lib.mi_gdfn_saved_bytes(C.byref(_gdfn_shape(y, hidden, 3, 0))), y.device)
+    L.check(lib.mi_gdfn_fused_fwd_train(C.byref(s), _p(pack), _p(y), _p(out), _p(mean), _p(rstd), _p(saved), _stream()),
+            "gdfn_fused_fwd_train")
+    return out, saved, mean, rstd
+
+
 def mdta_fused_ok(x: Tensor, heads: int, ks: int = 3) -> bool:
     """True when the one-launch LN -> qkv -> dw3x3 -> q k^T pass (csrc/fused_mdta.hip) covers this activation."""
     if x.dtype != torch.bfloat16 or ks != 3 or not x.is_cuda:

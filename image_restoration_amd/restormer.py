@@ -160,9 +160,18 @@ def _block_plan(x: Tensor, heads: int, params, need: bool) -> dict:
     tail_a = bool(tail_ok and ops.mdta_bwd_ln_ok(x, heads, ks_a, att[2] is not None))
     tail_f = bool(tail_ok and ops.gdfn_bwd_ln_ok(x, hidden, ks_f, ffn[1] is not None))
     head_ok = not ops.env("MI_NO_LN_HEAD")
-    return {"wb": wb, "tail_a": tail_a, "tail_f": tail_f,
+    # training forward of the second half-block in ONE launch (csrc/fused_gdfn.hip, SAVE form; needs the tail in backward - LN(y)
+    # is never written - and a covered plane).  OPT-IN (MI_FUSED_TRAIN=1): measured 0.85-0.99x of the chain at bs 32
+    # (profiles/r03_j_*: the chain streams at 4.4-5.1 TB/s, the one-launch kernel is issue-bound at 2 waves per SIMD and
+    # its 8 C planes of stores do not hide behind it)
+    fused_f = bool(need and tail_f and ops.env("MI_FUSED_TRAIN") and ops.gdfn_fused_train_ok(x, hidden, ks_f))
+    return {"wb": wb, "tail_a": tail_a, "tail_f": tail_f, "fused_f": fused_f,
             "head_a": bool(head_ok and (tail_a or not need) and ops.mdta_fwd_ln_ok(x, heads, ks_a)),
             "head_f": bool(head_ok and (tail_f or not need) and ops.gdfn_fwd_ln_ok(x, hidden, ks_f))}
+
+
+def hidden_of(ffn) -> int:
+    return ffn[4].shape[1]
 
 
 def _block_forward(x: Tensor, heads: int, params, need: bool):
@@ -179,7 +188,10 @@ def _block_forward(x: Tensor, heads: int, params, need: bool):
     else:
         xn, mean1, rstd1 = ops.ln_fwd(x, n1[0], n1[1], wb, want_stats=need)
         y, sv_a = ops.mdta_fwd(xn, x, att, heads, need)
-    if plan["head_f"]:
+    if plan["fused_f"]:
+        # (packed per call: the weights change every step; one small launch)
+        out, sv_f, mean2, rstd2 = ops.gdfn_fused_fwd_train(y, ops.gdfn_fused_pack(y, n2[0], n2[1], tuple(ffn)), hidden_of(ffn), wb)
+    elif plan["head_f"]:
         out, sv_f, mean2, rstd2 = ops.gdfn_fwd(y, y, ffn, need, ln=(n2[0], n2[1], need))
     else:
         yn, mean2, rstd2 = ops.ln_fwd(y, n2[0], n2[1], wb, want_stats=need)

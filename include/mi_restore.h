@@ -281,6 +281,13 @@ int mi_gdfn_fused_pack(const mi_gdfn_fused_shape* s, const float* ln_w, const fl
                        void* pack, void* stream);
 int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean,
                       float* rstd, void* stream);
+/* Training form of the same launch: besides out and the statistics it writes what mi_gdfn_bwd / mi_gdfn_bwd_ln read - the
+ * project_in output h0 [B,2h,H,W] and the gate output g [B,h,H,W] - into `saved`, a blob of mi_gdfn_saved_bytes() bytes for
+ * the mi_gdfn_shape {B, C, hidden, H, W, MI_BF16, 3, flags 0}: the forward of `x + ffn(norm2(x))` (Restormer.py:148) is ONE
+ * launch (10 C planes per pixel at hidden = 2.66 C) instead of GEMM -> depthwise gate -> GEMM (19).  _ok: covered shape. */
+int mi_gdfn_fused_fwd_train_ok(const mi_gdfn_fused_shape* s);
+int mi_gdfn_fused_fwd_train(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean,
+                            float* rstd, void* saved, void* stream);
 
 /* ------------------------------------------------------------------------
  * Backward tail of a half-block  out = x + F(LN(x)),  F starting in the 1x1 conv h = W LN(x)

@@ -439,3 +439,75 @@ def test_block_infer_takes_the_fused_mdta_kernel():
     sd2["attn.qkv.weight"] = sd2["attn.qkv.weight"] * 0.5
     ref2 = R.transformer_block(x.float().cpu().double(), {k: v.double() for k, v in sd2.items()}, heads, "WithBias")
     assert rel(y2, ref2) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ fused GDFN forward on the training path
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 32, 64)), (48, 1, (1, 48, 16, 128)), (96, 2, (2, 96, 16, 128)),
+                                           (96, 1, (1, 96, 24, 64))])
+def test_gdfn_fused_training_forward_saves_what_the_chain_saves(c, heads, shape):
+    """mi_gdfn_fused_fwd_train: out, the LayerNorm statistics and the saved blob (project_in output h0, gate output g) against
+    the chain mi_gdfn_fwd_ln on the same input.  Both round h0 and g to bf16 once from fp32 accumulators, so the blobs agree to
+    a bf16 ulp of the largest entry; out against the fp64 oracle within the bf16 bound."""
+    from image_restoration_amd import ops
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=61 + c)
+    g = torch.Generator().manual_seed(7)
+    sd["norm2.body.weight"] = 1.0 + 0.3 * torch.randn(c, generator=g)
+    sd["norm2.body.bias"] = 0.2 * torch.randn(c, generator=g)
+    yb = seeded_input(shape, 5100 + c).to(DEV).to(torch.bfloat16)
+    ln_w, ln_b = sd["norm2.body.weight"].to(DEV).float(), sd["norm2.body.bias"].to(DEV).float()
+    params = _ffn_params(sd, DEV)
+    hidden = params[4].shape[1]
+    assert ops.gdfn_fused_train_ok(yb, hidden)
+    out, saved, mean, rstd = ops.gdfn_fused_fwd_train(yb, ops.gdfn_fused_pack(yb, ln_w, ln_b, params), hidden, True)
+    out_c, saved_c, mean_c, rstd_c = ops.gdfn_fwd(yb, yb, params, True, ln=(ln_w, ln_b, True))
+    torch.cuda.synchronize()
+    assert saved.numel() == saved_c.numel()
+    B, _, H, W = shape
+    n_h0 = B * 2 * hidden * H * W
+    h0, h0_c = saved[: 2 * n_h0].view(torch.bfloat16).float(), saved_c[: 2 * n_h0].view(torch.bfloat16).float()
+    off_g = (2 * n_h0 + 255) // 256 * 256
+    gg, gg_c = (t[off_g: off_g + n_h0].view(torch.bfloat16).float() for t in (saved, saved_c))
+    assert rel(h0, h0_c) < 1.2e-2, rel(h0, h0_c)          # LN affine folded into W (fused) vs applied to x (chain): bf16 operand rounding
+    assert rel(gg, gg_c) < 2e-2, rel(gg, gg_c)
+    ref = _oracle_half_block(yb.float().cpu(), sd, "WithBias")
+    assert rel(out, ref) < 2e-2 and rel(out_c, ref) < 2e-2
+    assert rel(mean, mean_c) < 1e-5 and rel(rstd, rstd_c) < 1e-5
+    # h0 against the oracle's project_in(LN(y)) directly
+    d = {k: v.double() for k, v in sd.items()}
+    yn = R.layernorm_nchw(yb.float().cpu().double(), d["norm2.body.weight"], d["norm2.body.bias"], "WithBias")
+    h0_ref = torch.nn.functional.conv2d(yn, d["ffn.project_in.weight"])
+    assert rel(h0.view(B, 2 * hidden, H, W), h0_ref) < 1.2e-2
+
+
+@pytest.mark.parametrize("c,heads,shape", [(48, 1, (2, 48, 32, 64)), (96, 2, (2, 96, 16, 64))])
+def test_block_training_step_with_fused_gdfn_forward(c, heads, shape, monkeypatch):
+    """TransformerBlock forward + backward with the second half-block's forward in one launch (MI_FUSED_TRAIN=1) and on the
+    chain (default): dx and every parameter gradient within the bf16 bound of the fp64 oracle in both modes."""
+    m = M()
+    from image_restoration_amd import restormer
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=71 + c)
+    x0, cot = seeded_input(shape, 7100 + c), seeded_input(shape, 7101 + c)
+    xr = x0.double().requires_grad_(True)
+    ps = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref_out = R.transformer_block(xr, ps, heads, "WithBias")
+    ref_out.backward(cot.double())
+    outs = {}
+    for mode in ("fused", "chain"):
+        if mode == "fused":
+            monkeypatch.setenv("MI_FUSED_TRAIN", "1")
+        else:
+            monkeypatch.delenv("MI_FUSED_TRAIN")
+        m.reload_env()
+        blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)
+        blk.load_state_dict(sd)
+        x = x0.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        params = blk.norm1._params() + blk.attn._params() + blk.norm2._params() + blk.ffn._params()
+        assert restormer._block_plan(x, heads, params, True)["fused_f"] == (mode == "fused")
+        y = blk(x)
+        y.backward(cot.to(DEV).to(torch.bfloat16))
+        outs[mode] = y
+        assert rel(y, ref_out) < 2e-2, (mode, rel(y, ref_out))
+        assert rel(x.grad, xr.grad) < 3e-2, (mode, rel(x.grad, xr.grad))
+        for k, p in blk.named_parameters():
+            assert rel(p.grad, ps[k].grad) < 3e-2, (mode, k, rel(p.grad, ps[k].grad))
+    assert rel(outs["fused"], outs["chain"].float()) < 2e-2

@@ -55,6 +55,27 @@ def gdfn():
               f"{flops / tf / 1e6:6.1f} TF/s)   chain {tc:8.1f} us   speed-up {tc / tf:4.2f}x", flush=True)
 
 
+def gdfn_train():
+    """Training forward of the LN + GDFN half-block: one launch that also writes h0 and g (mi_gdfn_fused_fwd_train, incl. its
+    per-step weight pack) against the chain mi_gdfn_fwd_ln (LN inside the project_in GEMM -> depthwise gate -> project_out)."""
+    for C, H, W, h in SHAPES:
+        torch.manual_seed(0)
+        y = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16)
+        ln_w = 1 + 0.1 * torch.randn(C, device=DEV)
+        ln_b = 0.1 * torch.randn(C, device=DEV)
+        params = (torch.randn(2 * h, C, 1, 1, device=DEV) / C ** 0.5, None, torch.randn(2 * h, 1, 3, 3, device=DEV) / 3, None,
+                  torch.randn(C, h, 1, 1, device=DEV) / h ** 0.5, None)
+        pack = ops.gdfn_fused_pack(y, ln_w, ln_b, params)
+        fused = lambda: ops.gdfn_fused_fwd_train(y, ops.gdfn_fused_pack(y, ln_w, ln_b, params), h, True)
+        infer = lambda: ops.gdfn_fused_fwd(y, pack, h, True, want_stats=True)
+        chain = lambda: ops.gdfn_fwd(y, y, params, True, ln=(ln_w, ln_b, True))
+        tf, ti, tc = timeit(fused), timeit(infer), timeit(chain)
+        unit = 2.0 * B * C * H * W
+        print(f"gdfn TRAINING fwd C={C} {H}x{W} h={h} bs={B}: one launch + saves {tf:8.1f} us ({(2 + 3.0 * h / C) * unit / tf / 1e6:5.2f} TB/s "
+              f"alg)   same kernel without the saves {ti:8.1f} us   chain {tc:8.1f} us ({(5 + 6.0 * h / C) * unit / tc / 1e6:5.2f} TB/s alg)   "
+              f"speed-up {tc / tf:4.2f}x", flush=True)
+
+
 def mdta():
     """Fused pass A (LN -> qkv -> dw3x3 -> q k^T partials + v) + partial sum + fold + M v, against the unfused chain
     (qkv GEMM with LN on load, dw3x3, streaming Gram, fold, M v)."""
@@ -96,4 +117,4 @@ def mdta():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "gdfn"
-    {"gdfn": gdfn, "mdta": mdta}[which]()
+    {"gdfn": gdfn, "gdfn_train": gdfn_train, "mdta": mdta}[which]()
