@@ -203,6 +203,7 @@ SIGNATURES = {
     "mi_gdfn_fused_fwd_train": (C.c_int, [C.POINTER(GdfnFusedShape), vp, vp, vp, fp, fp, vp, vp]),
     "mi_gdfn_fused_fwd_f8": (C.c_int, [C.POINTER(GdfnFusedShape), vp, C.POINTER(F8Scales), vp, vp, vp]),
     "mi_mdta_fused_ok": (C.c_int, [C.POINTER(MdtaShape)]),
+    "mi_mdta_fused_pays": (C.c_int, [C.POINTER(MdtaShape)]),
     "mi_mdta_fused_pack_bytes": (C.c_size_t, [C.POINTER(MdtaShape)]),
     "mi_mdta_fused_pack": (C.c_int, [C.POINTER(MdtaShape), fp, fp, C.POINTER(MdtaParams), vp, vp]),
     "mi_mdta_fused_workspace": (C.c_size_t, [C.POINTER(MdtaShape)]),
@@ -215,6 +216,12 @@ SIGNATURES = {
     "mi_rows_dot_workspace": (C.c_size_t, [C.c_int, c_i64]),
     "mi_rows_dot": (C.c_int, [fp, vp, vp, fp, C.c_int, c_i64, C.c_int, vp, vp]),
     "mi_glue3x3_ok": (C.c_int, [C.c_int, C.c_int]),
+    "mi_conv3x3_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mi_conv3x3_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mi_conv3x3_pack": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mi_conv3x3_fwd": (C.c_int, [vp, vp, C.c_int64, fp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mi_conv3x3_wgrad_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi_conv3x3_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_grouped_pw_gemm": (C.c_int, [C.POINTER(GroupedProblem), C.c_int, vp, vp, C.c_int, c_i64, C.c_int, vp]),

@@ -607,6 +607,13 @@ static int fm_launch(const mi_mdta_shape* s, const FmPackLayout& l, const void* 
 using namespace mi;
 
 extern "C" int mi_mdta_fused_ok(const mi_mdta_shape* s) { return (fm_kind(s) != FM_NONE && !MI_ENV(MI_NO_FUSED_MDTA)) ? 1 : 0; }
+// Covered AND expected to beat the unfused chain: pass A runs one persistent 8-wave workgroup per CU, so it needs (close to) a
+// workgroup for every CU - B * splits >= 192 of the 256.  Measured (profiles/r03_c_*): bs 8 at 96 x 128^2 gives 128 workgroups and
+// 0.75x of the chain; bs 8 at 256^2 and bs 25 / 32 everywhere fill the chip (1.06 - 1.18x).
+extern "C" int mi_mdta_fused_pays(const mi_mdta_shape* s) {
+  if (!mi_mdta_fused_ok(s)) return 0;
+  return (int64_t)s->B * fm_splits(s, 8) >= 192 ? 1 : 0;
+}
 
 extern "C" size_t mi_mdta_fused_pack_bytes(const mi_mdta_shape* s) {
   if (fm_kind(s) == FM_NONE) return 0;

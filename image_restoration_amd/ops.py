@@ -617,6 +617,13 @@ def mdta_fused_ok(x: Tensor, heads: int, ks: int = 3) -> bool:
     return bool(L.lib().mi_mdta_fused_ok(C.byref(_mdta_shape(x, heads, ks))))
 
 
+def mdta_fused_pays(x: Tensor, heads: int, ks: int = 3) -> bool:
+    """Covered and large enough (one workgroup for nearly every CU) for the fused pass to beat the unfused chain."""
+    if x.dtype != torch.bfloat16 or ks != 3 or not x.is_cuda:
+        return False
+    return bool(L.lib().mi_mdta_fused_pays(C.byref(_mdta_shape(x, heads, ks))))
+
+
 def mdta_fused_pack(x_like: Tensor, heads: int, ln_w: Tensor, ln_b: Optional[Tensor], params: "MdtaParamsT") -> Tensor:
     """LayerNorm affine + qkv / depthwise parameters -> the fused MDTA kernel's packed weight images."""
     _gpu(ln_w, ln_b, *params)
@@ -717,6 +724,62 @@ def col2im3x3(z: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tenso
     y = torch.empty((B, M, H, W), dtype=z.dtype, device=z.device)
     L.check(L.lib().mi_col2im3x3(_p(z), _p(_f32(bias, "bias")), _p(residual), _p(y), B, M, H, W, 1 if flip else 0, _dt(z), _stream()), "col2im3x3")
     return y
+
+
+def conv3x3_ok(x: Tensor) -> bool:
+    """The implicit-GEMM 3x3 convolution covers this activation (bf16, W % 8 == 0; csrc/conv3x3.hip)."""
+    return bool(x.is_cuda and x.dim() == 4 and L.lib().mi_conv3x3_ok(x.shape[2], x.shape[3], _dt(x)))
+
+
+def conv3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+            transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Dense 3x3 conv (stride 1, pad 1) of x [B,K,H,W] as an implicit GEMM.  transpose False: weight [M,K,3,3], y = conv(x).
+    transpose True: weight is the conv's own [K,M,3,3] and the result is its data gradient for the upstream gradient x.
+    x / residual / out may be channel slices (dense [C,H,W] blocks, any batch stride)."""
+    _gpu(weight, bias)
+    for tsr in (x, residual, out):                       # channel slices allowed: checked for dense [C,H,W] blocks below
+        if tsr is not None and not tsr.is_cuda:
+            raise RuntimeError("image_restoration_amd ops run on the MI355X only (got a CPU tensor)")
+    _f32(weight, "conv weight")
+    B, K, H, W = x.shape
+    M = weight.shape[1] if transpose else weight.shape[0]
+    if (weight.shape[0] if transpose else weight.shape[1]) != K or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError(f"conv3x3: weight {tuple(weight.shape)} does not match {K} input channels")
+    for tsr, name in ((x, "x"), (residual, "residual"), (out, "out")):
+        if tsr is not None and not (tsr.stride(3) == 1 and tsr.stride(2) == W and tsr.stride(1) == H * W):
+            raise ValueError(f"conv3x3: {name} must have dense [C,H,W] blocks")
+    lib = L.lib()
+    w = weight.contiguous()
+    pack = _blob(lib.mi_conv3x3_pack_bytes(M, K), x.device)
+    L.check(lib.mi_conv3x3_pack(_p(w), M, K, 1 if transpose else 0, _p(pack), _stream()), "conv3x3_pack")
+    y = out if out is not None else torch.empty((B, M, H, W), dtype=x.dtype, device=x.device)
+    L.check(lib.mi_conv3x3_fwd(_p(pack), _p(x), x.stride(0), _p(_f32(bias, "bias")), _p(residual),
+                               residual.stride(0) if residual is not None else 0, _p(y), y.stride(0), B, M, K, H, W, _stream()),
+            "conv3x3_fwd")
+    return y
+
+
+def conv3x3_wgrad(dy: Tensor, x: Tensor, dw: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """Weight gradient of the dense 3x3 conv: dw[M,K,3,3] (+)= sum over batch and pixels of dy[b,m,p] x[b,k,p+d(tap)] without the
+    im2col expansion.  dy [B,M,H,W], x [B,K,H,W] bf16 (channel slices allowed); dw fp32 (allocated when None)."""
+    _gpu(dw)
+    for tsr, name in ((dy, "dy"), (x, "x")):
+        if not tsr.is_cuda:
+            raise RuntimeError("image_restoration_amd ops run on the MI355X only (got a CPU tensor)")
+        if not (tsr.stride(3) == 1 and tsr.stride(2) == tsr.shape[3] and tsr.stride(1) == tsr.shape[2] * tsr.shape[3]):
+            raise ValueError(f"conv3x3_wgrad: {name} must have dense [C,H,W] blocks")
+    B, M, H, W = dy.shape
+    K = x.shape[1]
+    if dw is None:
+        if accumulate:
+            raise ValueError("conv3x3_wgrad: accumulate needs the gradient buffer")
+        dw = torch.empty((M, K, 3, 3), dtype=torch.float32, device=dy.device)
+    _f32(dw, "conv weight gradient")
+    lib = L.lib()
+    ws = _ws(lib.mi_conv3x3_wgrad_workspace(B, M, K, H, W), dy.device)
+    L.check(lib.mi_conv3x3_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), 1 if accumulate else 0, B, M, K, H, W, _p(ws),
+                                 _stream()), "conv3x3_wgrad")
+    return dw
 
 
 def pixel_shuffle2(x: Tensor, unshuffle: bool, out: Optional[Tensor] = None) -> Tensor:

@@ -384,8 +384,11 @@ def _block_infer(block, x: Tensor, params) -> Tensor:
     f8_a = block._f8["attn"] if mode and ops.mdta_fwd_f8_ok(x, heads, ks_a, bool(ln_a)) else None
     if mode:
         F8_COUNTS["f8" if f8_a else "bf16"] += 2
-    if f8_a is None and ops.mdta_fused_ok(x, heads, ks_a) and not ops.env("MI_NO_FUSED_INFER"):
-        # pass A in one launch: LN -> qkv -> dw3x3 -> q k^T partials; only v is written (q, k, qkv0 never reach HBM)
+    if (f8_a is None and not ops.env("MI_NO_FUSED_INFER") and ops.mdta_fused_ok(x, heads, ks_a)
+            and (ops.mdta_fused_pays(x, heads, ks_a) or ops.env("MI_FUSED_MDTA_ALWAYS"))):
+        # pass A in one launch: LN -> qkv -> dw3x3 -> q k^T partials; only v is written (q, k, qkv0 never reach HBM).  Taken
+        # where it fills the chip (one persistent workgroup per CU: mi_mdta_fused_pays); small batches of small planes stay on
+        # the chain, which is faster there (MI_FUSED_MDTA_ALWAYS=1 forces it: tests)
         y = ops.mdta_fused_fwd(x, _fused_mdta_pack(block, x, heads, n1, att), att, heads, wb, x)[0]
     elif ln_a:
         y = ops.mdta_fwd(x, x, att, heads, False, ln=(n1[0], n1[1], False), f8=f8_a)
@@ -657,8 +660,9 @@ class TransformerBlock(nn.Module):
 
 
 class _Conv3x3Fn(torch.autograd.Function):
-    """Dense 3x3 convolution (stride 1, pad 1) built from the native 1x1 GEMM / Gram plus the im2col3x3 / col2im3x3 layout
-    kernels (csrc/glue.hip): Restormer's OverlapPatchEmbed (3 -> dim, Restormer.py:156-165), output conv (2*dim -> 3 plus the
+    """Dense 3x3 convolution (stride 1, pad 1).  bf16 planes with W % 8 == 0 take the implicit-GEMM kernels (csrc/conv3x3.hip:
+    forward, data gradient and weight gradient without the 9-plane expansion in HBM); everything else (fp32 - the exact parity
+    path -, odd widths) is built from the native 1x1 GEMM / Gram plus the im2col3x3 / col2im3x3 layout kernels (csrc/glue.hip): Restormer's OverlapPatchEmbed (3 -> dim, Restormer.py:156-165), output conv (2*dim -> 3 plus the
     input residual, :243,281) and the C -> C/2 / C -> 2C convs of Downsample / Upsample (:171-189).  The form with the
     fewer expanded planes is taken (im2col when Cin <= Cout, col2im otherwise), so no vendor convolution runs in the step.
       Cin tiny : y = W[Cout,9Cin] . im2col(x);            dW = Gram(dy, im2col(x));  dx = col2im(W^T . dy)
@@ -667,6 +671,19 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         cout, cin = weight.shape[0], weight.shape[1]
+        # (a 2..3-channel OUTPUT - the network's last conv - stays on the col2im form: 16-row MFMA tiles would be 80 % padding,
+        #  measured 0.39x; profiles/r03_o_*)
+        ctx.implicit = bool(cout >= 16 and ops.conv3x3_ok(x) and ops_dense(x) and (residual is None or ops_dense(residual))
+                            and not ops.env("MI_NO_CONV3_IMPLICIT"))
+        if ctx.implicit:
+            # implicit GEMM (csrc/conv3x3.hip): no 9-plane expansion in HBM; backward = the same kernel on the flipped /
+            # transposed weight pack (dx) + the pixel-contraction kernel (dW)
+            y = ops.conv3x3(x, weight, bias, residual)
+            if _grad_mode() and any(ctx.needs_input_grad):
+                ctx.save_for_backward(x, weight)
+                ctx.has_bias = bias is not None
+                ctx.mg = _main_grads((weight, bias))
+            return y
         ctx.small_in = cin <= cout
         if ctx.small_in:
             xcol = ops.im2col3x3(x)
@@ -692,6 +709,18 @@ class _Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous()
         cout, cin = weight.shape[0], weight.shape[1]
         dx = None
+        if ctx.implicit:
+            acc = ctx.mg is not None
+            dw = ops.conv3x3_wgrad(dy, saved, ctx.mg[0] if acc else None, acc)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv3x3(dy, weight, transpose=True)
+            db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
+            dres = dy if ctx.needs_input_grad[3] else None
+            if acc:
+                if db is not None:
+                    ctx.mg[1].add_(db)
+                return dx, None, None, dres
+            return dx, dw, db, dres
         if ctx.small_in:
             if ctx.recol:
                 saved = ops.im2col3x3(saved)

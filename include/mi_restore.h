@@ -346,6 +346,7 @@ int mi_gdfn_fused_fwd_f8(const mi_gdfn_fused_shape* s, const void* pack, const m
  *  ws   : mi_mdta_fused_workspace() bytes (v, the partials, the c x c matrices).
  * ------------------------------------------------------------------------ */
 int mi_mdta_fused_ok(const mi_mdta_shape* s);
+int mi_mdta_fused_pays(const mi_mdta_shape* s);   /* covered and enough workgroups (B x splits >= 192) to beat the unfused chain */
 size_t mi_mdta_fused_pack_bytes(const mi_mdta_shape* s);
 int mi_mdta_fused_pack(const mi_mdta_shape* s, const float* ln_w, const float* ln_b, const mi_mdta_params* p, void* pack,
                        void* stream);
@@ -524,6 +525,27 @@ int mi_glue3x3_ok(int H, int W);
 int mi_im2col3x3(const void* x, void* out, int B, int C, int H, int W, int flip, int dtype, void* stream);
 int mi_col2im3x3(const void* z, const float* bias, const void* residual, void* y, int B, int M, int H, int W, int flip,
                  int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dense 3x3 convolution (stride 1, zero padding 1) as an implicit GEMM (csrc/conv3x3.hip): the glue convs above and the
+ * C -> C/2 / C -> 2C bodies of Downsample / Upsample (Restormer.py:171-189) without the 9-plane im2col expansion in HBM.
+ * bf16 activations, fp32 accumulate, W % 8 == 0 (mi_conv3x3_ok); other planes / fp32 use the im2col forms above.
+ *   mi_conv3x3_pack : w fp32 -> the kernel's fragment-major bf16 image (mi_conv3x3_pack_bytes(M, K) bytes; re-pack after every
+ *                     weight update).  transpose_flip == 0: w is [M][K][3][3] and the op is y = conv(x; w).
+ *                     transpose_flip != 0: w is the conv's own weight [K][M][3][3] and the op is its DATA GRADIENT
+ *                     dx[M planes] = conv_transpose(dy[K planes]; w)  (taps flipped, channel roles swapped).
+ *   mi_conv3x3_fwd  : y[B,M,H,W] = conv(x[B,K,H,W]) (+ bias[m]) (+ residual[B,M,H,W]); x_bs / r_bs / y_bs batch strides in
+ *                     elements (0 = dense) so operands may be channel slices; channel planes dense H*W.
+ *   mi_conv3x3_wgrad: dw[M][K][3][3] (+)= sum_{b,p} dy[b][m][p] . x[b][k][p + d(tap)]; ws = mi_conv3x3_wgrad_workspace bytes.
+ * ------------------------------------------------------------------------ */
+int mi_conv3x3_ok(int H, int W, int dtype);
+size_t mi_conv3x3_pack_bytes(int M, int K);
+int mi_conv3x3_pack(const float* w, int M, int K, int transpose_flip, void* pack, void* stream);
+int mi_conv3x3_fwd(const void* pack, const void* x, int64_t x_bs, const float* bias, const void* residual, int64_t r_bs,
+                   void* y, int64_t y_bs, int B, int M, int K, int H, int W, void* stream);
+size_t mi_conv3x3_wgrad_workspace(int B, int M, int K, int H, int W);
+int mi_conv3x3_wgrad(const void* dy, int64_t dy_bs, const void* x, int64_t x_bs, float* dw, int accumulate, int B, int M, int K,
+                     int H, int W, void* ws, void* stream);
 
 /* PixelShuffle(2) / PixelUnshuffle(2) of Upsample / Downsample (Restormer.py:171-189; moce_ir.py Downsample/Upsample):
  *   unshuffle == 0: in [B,4c,H,W] -> out [B,c,2H,2W], out[b][c][2y+i][2x+j] = in[b][4c+2i+j][y][x]

@@ -419,9 +419,18 @@ def test_mdta_fused_pass_a_vs_oracle_and_chain(c, heads, bias, kind, shape):
     assert torch.equal(y, y2)                                # fixed-order partial sums: bit-reproducible
 
 
-def test_block_infer_takes_the_fused_mdta_kernel():
-    """TransformerBlock.forward under no_grad: both halves are one-launch kernels where the shapes allow; output vs the oracle."""
+def test_block_infer_takes_the_fused_mdta_kernel(monkeypatch):
+    """TransformerBlock.forward under no_grad: both halves are one-launch kernels where the shapes allow; output vs the oracle.
+    (The fused MDTA pass is taken by default only where it fills the chip - mi_mdta_fused_pays; this small case forces it.)"""
     m = M()
+    from image_restoration_amd import ops
+    small = torch.zeros((2, 96, 32, 64), dtype=torch.bfloat16, device=DEV)
+    big = torch.zeros((8, 96, 256, 256), dtype=torch.bfloat16, device=DEV)
+    assert ops.mdta_fused_ok(small, 1) and not ops.mdta_fused_pays(small, 1) and ops.mdta_fused_pays(big, 1)
+    assert not ops.mdta_fused_pays(torch.zeros((8, 96, 128, 128), dtype=torch.bfloat16, device=DEV), 2)   # 128 workgroups: the chain wins
+    del big
+    monkeypatch.setenv("MI_FUSED_MDTA_ALWAYS", "1")
+    m.reload_env()
     c, heads, shape = 96, 1, (2, 96, 32, 64)
     sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=141)
     blk = m.TransformerBlock(c, heads, 2.66, False, "WithBias").to(DEV)

@@ -331,7 +331,9 @@ def test_deferred_gradient_reductions_match_the_immediate_ones(monkeypatch):
     # cannot be compared this tightly: after an AdamW step on gradients that differ in the last bit, bf16 rounding flips inside
     # the network move individual gradient elements by 1e-3.)
     assert rel(g1[0], g0[0]) < 1e-5, rel(g1[0], g0[0])
-    assert rel(p1, p0) < 1e-2
+    # parameters after two AdamW steps: step 1 moves every weight by lr * sign-like m / sqrt(v), so a gradient that is zero up to
+    # summation order may flip one weight by 2 lr; all but a sliver of the weights agree
+    assert float(((p1 - p0).abs() > 1e-3).float().mean()) < 0.01
     # outside a trainer's window nothing is deferred: main_grad accumulation is visible right after backward
     blk = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
     tr = FlatTrainer(blk, lr=1e-2)
