@@ -50,6 +50,10 @@ size_t bwd_tail_workspace(int M, int C);
 int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dres, const float* mean, const float* rstd,
                     const float* w, const float* gamma, const float* beta, void* dx, float* dw, float* dgamma, float* dbeta,
                     int B, int64_t N, int accumulate, void* ws, hipStream_t st);
+// ---- LDS-tiled 1x1 GEMM for deep K (pw_lds.hip); mi_pw_gemm hands it the shapes pw_lds_ok accepts ----
+bool pw_lds_ok(const mi_pw_desc* d);
+size_t pw_lds_pack_bytes(const mi_pw_desc* d);
+int pw_lds_launch(const mi_pw_desc* d, void* ws, hipStream_t st);
 // ---- fused GDFN forward, training form (fused_gdfn.hip): also writes h0 [B][2h][H][W] and g [B][h][H][W] ----
 int fused_gdfn_fwd_save(const mi_gdfn_fused_shape* s, const void* pack, const void* y, void* out, float* mean, float* rstd,
                         void* h0, void* g, hipStream_t st);

@@ -1468,12 +1468,15 @@ extern "C" size_t mi_pw_gemm_workspace(const mi_pw_desc* d) {
   // the wave-owned forms tile the packed image differently; which form runs depends on pointer alignment at call time, and module
   // entry points size their workspaces before they see the pointers: cover both
   const size_t a = pw_plan(d).bytes, b = pw_plan(d, false).bytes;
-  return a > b ? a : b;
+  const size_t c = (d->dtype == MI_BF16 && d->k1 > 128) ? align_up(pw_lds_pack_bytes(d), 256) : 0;   // the LDS-tiled kernel's image
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 
 extern "C" int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream) {
   MI_TRY(pw_check(d));
   MI_CHECK_ARG(ws && aligned16(ws), "pw_gemm: workspace missing or not 16-byte aligned");
+  if (pw_lds_ok(d)) return pw_lds_launch(d, ws, (hipStream_t)stream);     // deep K: the LDS-tiled kernel (pw_lds.hip)
   PwK k;
   k.x1 = d->x1; k.x1_bs = d->x1_bs; k.x1_gs = d->x1_gs; k.k1 = d->k1;
   k.x2 = d->x2; k.x2_bs = d->x2_bs; k.x2_gs = d->x2_gs; k.k2 = d->k2;

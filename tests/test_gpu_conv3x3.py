@@ -136,3 +136,44 @@ def test_glue_conv_module_both_routes(cin, cout, hw, res, monkeypatch):
         assert rel(c.bias.grad, br.grad) < 1.5e-2, route
         if res:
             assert rel(r.grad, rr.grad) < 1e-6, route
+
+
+# ------------------------------------------------------------------------------------------------ LDS-tiled 1x1 GEMM for deep K (csrc/pw_lds.hip)
+@pytest.mark.parametrize("B,M,K,hw,tr,bias,res", [
+    (2, 1152, 384, (32, 32), False, False, False),      # latent qkv
+    (2, 2042, 384, (32, 32), False, True, False),       # latent project_in (M = 2042: ragged last tile), bias
+    (2, 384, 1021, (32, 32), False, False, True),       # latent project_out: K = 1021 (ragged last chunk), residual
+    (1, 1020, 192, (64, 64), False, False, False),      # level 3 project_in
+    (2, 192, 510, (16, 32), False, True, True),         # level 3 project_out on a 512-pixel plane
+    (2, 384, 2042, (32, 32), True, False, False),       # backward of project_in: W^T, K = 2042
+    (1, 1021, 384, (20, 24), True, False, False),       # backward of project_out; 480-pixel plane (partial pixel tile)
+    (3, 128, 129, (16, 16), False, False, False),       # the smallest shape the kernel takes
+])
+def test_deep_1x1_gemm_vs_fp64(B, M, K, hw, tr, bias, res, monkeypatch):
+    """ops.conv1x1 on the shapes mi_pw_gemm hands to the LDS-tiled kernel (bf16, K > 128, M >= 128), against fp64 on the same
+    bf16-rounded operands, and against the kernels it replaces (MI_NO_PW_LDS=1): both within the bf16 output rounding."""
+    import image_restoration_amd as m
+    from image_restoration_amd import ops
+    g = torch.Generator().manual_seed(500 + M + K)
+    x = torch.randn((B, K) + hw, generator=g).to(torch.bfloat16)
+    w = (torch.randn((K, M) if tr else (M, K), generator=g) / K ** 0.5).to(torch.bfloat16).float()
+    bv = torch.randn(M, generator=g) if bias else None
+    rv = torch.randn((B, M) + hw, generator=g).to(torch.bfloat16) if res else None
+    wm = w.t() if tr else w
+    ref = torch.einsum("mk,bkhw->bmhw", wm.double(), x.double())
+    if bias:
+        ref = ref + bv.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + rv.double()
+    outs = {}
+    monkeypatch.setenv("MI_PW_LDS", "all")                 # every covered shape, not only the ones where it is the faster kernel
+    for mode in ("lds", "old"):
+        if mode == "old":
+            monkeypatch.setenv("MI_NO_PW_LDS", "1")
+        else:
+            monkeypatch.delenv("MI_NO_PW_LDS", raising=False)
+        m.reload_env()
+        outs[mode] = ops.conv1x1(x.to(DEV), w.to(DEV), bv.to(DEV) if bias else None, rv.to(DEV) if res else None, transposed=tr)
+        torch.cuda.synchronize()
+        assert rel(outs[mode], ref) < 1e-2, (mode, rel(outs[mode], ref))
+    assert rel(outs["lds"], outs["old"].float()) < 1e-2
