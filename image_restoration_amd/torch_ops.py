@@ -12,8 +12,9 @@ forward / backward pair with a fake (meta) implementation and ``register_autogra
 The forward ops return ``[out, saved...]``: what the backward needs (LayerNorm statistics, the kernels' saved-for-backward
 blobs) are op OUTPUTS, as the custom-op autograd contract wants; ``register_autograd`` stores them and calls the backward op.
 Under the ops sit the same helpers the ``torch.autograd.Function`` nodes of ``restormer.py`` use (``_block_forward`` /
-``_block_backward``, ``ops.mdta_fwd`` ...): one implementation, two front doors.  The modules take this door by default
-(``MI_TORCH_OPS=0`` selects the bare autograd.Function nodes - an A/B switch for the dispatch overhead).
+``_block_backward``, ``ops.mdta_fwd`` ...): one implementation, two front doors
+(modules route through these ops while torch.compile traces and with ``MI_TORCH_OPS=1``; eager calls take the bare
+autograd.Function nodes over the same implementation: restormer._use_torch_ops).
 
 Arguments shared by all forward ops: ``need`` - build what backward needs (the caller's grad mode; an op body always runs
 with grad mode off and cannot see it); ``accumulate`` (backward ops) - parameter gradients are ADDED into each parameter's

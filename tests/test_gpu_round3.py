@@ -263,8 +263,8 @@ def test_custom_ops_pass_opcheck(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
 def test_custom_op_route_equals_autograd_function_route(monkeypatch, dtype, bias):
-    """The modules' default door (mi_restore:: custom ops) and the bare autograd.Function nodes (MI_TORCH_OPS=0) run the same
-    kernels: outputs and every gradient bit-identical, for the block and for the three stand-alone modules."""
+    """The mi_restore:: custom-op door (MI_TORCH_OPS=1; also taken while torch.compile traces) and the bare autograd.Function
+    nodes (eager default, MI_TORCH_OPS=0) run the same kernels: outputs and every gradient bit-identical, for the block and for the three stand-alone modules."""
     def run(mod_fn, x0):
         mod, args = mod_fn()
         xs = [a.clone().requires_grad_(True) for a in args]
@@ -282,7 +282,7 @@ def test_custom_op_route_equals_autograd_function_route(monkeypatch, dtype, bias
         return f
     for make in (mk(m.TransformerBlock, 48, 2, 2.66, bias, "WithBias"), mk(m.LayerNorm, 48, "BiasFree"),
                  mk(m.Attention, 48, 2, bias), mk(m.FeedForward, 48, 2.66, bias)):
-        monkeypatch.delenv("MI_TORCH_OPS", raising=False)
+        monkeypatch.setenv("MI_TORCH_OPS", "1")
         a = run(make, x)
         monkeypatch.setenv("MI_TORCH_OPS", "0")
         b = run(make, x)
