@@ -117,7 +117,7 @@ def cpu_baseline():
     """The CPU oracle's training step, fp32, on this box's host cores (SURVEY 8(d) / BASELINE.md s.3: 1 x 3 x 256^2).
     A thread sweep on a 128^2 patch (16 / 8 threads: oneDNN's small convolutions do not scale to a whole socket - round 2
     measured all 64 threads 5-10x slower) picks the thread count; the quoted value is forward + L1 + backward on ONE
-    256 x 256 patch at that setting, warm-up + median of 3, with the forward-only rate beside it.  ~30 s in all."""
+    256 x 256 patch at that setting, warm-up + median of 2, with the forward-only rate beside it.  ~30 s in all."""
     from image_restoration_amd.configs import RESTORMER_BASE as cfg
     from oracle import restormer_ref as R
     sd = {k: v.requires_grad_(True) for k, v in R.make_restormer_state(cfg, seed=0).items()}
@@ -153,11 +153,11 @@ def cpu_baseline():
     best = min((t for t in sweep if "train_s" in sweep[t]), key=lambda t: sweep[t]["train_s"])
     torch.set_num_threads(best)
     big = data(256)
-    fwd256, train256 = med(fwd, big), med(train, big)
+    fwd256, train256 = med(fwd, big), med(train, big, n=2)   # (6 s per training step on this host: warm-up + 2)
     px128, px256 = 128 * 128 / 1e6, 256 * 256 / 1e6
     return {"value": round(px256 / train256, 6), "unit": "Mpixels/s", "cores": best, "kind": "port",
             "sample": f"oracle.restormer_forward + L1 + backward (Restormer base, fp32) on one 1x3x256x256 patch, {best} threads, "
-                      f"warm-up + median of 3; thread count picked by a 128x128 sweep; whole leg {time.perf_counter() - t_start:.1f} s",
+                      f"warm-up + median of 2 (forward: of 3); thread count picked by a 128x128 sweep; whole leg {time.perf_counter() - t_start:.1f} s",
             "fwd_mpix_s_256": round(px256 / fwd256, 6),
             "sweep_128": {"train_mpix_s": {str(t): round(px128 / r["train_s"], 6) for t, r in sweep.items() if "train_s" in r},
                           "fwd_mpix_s": {str(t): round(px128 / r["fwd_s"], 6) for t, r in sweep.items()}}}
