@@ -222,6 +222,8 @@ SIGNATURES = {
     "mi_conv3x3_fwd": (C.c_int, [vp, vp, C.c_int64, fp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_conv3x3_wgrad_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mi_conv3x3_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mi_chan_sum_workspace": (C.c_size_t, [C.c_int, C.c_int64]),
+    "mi_chan_sum": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]),
     "mi_im2col3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_col2im3x3": (C.c_int, [vp, fp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi_grouped_pw_gemm": (C.c_int, [C.POINTER(GroupedProblem), C.c_int, vp, vp, C.c_int, c_i64, C.c_int, vp]),

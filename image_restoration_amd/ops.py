@@ -726,6 +726,21 @@ def col2im3x3(z: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tenso
     return y
 
 
+def chan_sum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """Bias gradient of a conv: out[c] (+)= sum over batch and pixels of x[b, c] (fp32, fixed order)."""
+    _gpu(x, out)
+    B, Cn, H, W = x.shape
+    if out is None:
+        if accumulate:
+            raise ValueError("chan_sum: accumulate needs the gradient buffer")
+        out = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    _f32(out, "bias gradient")
+    lib = L.lib()
+    ws = _ws(lib.mi_chan_sum_workspace(Cn, H * W), x.device)
+    L.check(lib.mi_chan_sum(_p(x), _p(out), B, Cn, H * W, _dt(x), 1 if accumulate else 0, _p(ws), _stream()), "chan_sum")
+    return out
+
+
 def conv3x3_ok(x: Tensor) -> bool:
     """The implicit-GEMM 3x3 convolution covers this activation (bf16, W % 8 == 0; csrc/conv3x3.hip)."""
     return bool(x.is_cuda and x.dim() == 4 and L.lib().mi_conv3x3_ok(x.shape[2], x.shape[3], _dt(x)))

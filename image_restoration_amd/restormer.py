@@ -508,11 +508,10 @@ class _Conv1x1Fn(torch.autograd.Function):
         _wgrad_panels(dy, x1, x2, dw.reshape(w2.shape), acc)
         db = None
         if ctx.has_bias:
-            s = dy.float().sum(dim=(0, 2, 3))
             if acc:
-                ctx.mg[1].add_(s)
+                ops.chan_sum(dy, ctx.mg[1], True)
             else:
-                db = s
+                db = ops.chan_sum(dy)
         return dx1, dx2, (None if acc else dw), db
 
 
@@ -722,11 +721,11 @@ class _Conv3x3Fn(torch.autograd.Function):
             dw = ops.conv3x3_wgrad(dy, saved, ctx.mg[0] if acc else None, acc)
             if ctx.needs_input_grad[0]:
                 dx = ops.conv3x3(dy, weight, transpose=True)
-            db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
+            db = None
+            if ctx.has_bias:
+                db = ops.chan_sum(dy, ctx.mg[1] if acc else None, acc)
             dres = dy if ctx.needs_input_grad[3] else None
             if acc:
-                if db is not None:
-                    ctx.mg[1].add_(db)
                 return dx, None, None, dres
             return dx, dw, db, dres
         if ctx.small_in:
@@ -742,12 +741,12 @@ class _Conv3x3Fn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 wz = weight.permute(0, 2, 3, 1).reshape(cout * 9, cin).contiguous()
                 dx = ops.conv1x1(dz, wz, None, None, True)
-        db = dy.float().sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        db = None
+        if ctx.has_bias:
+            db = ops.chan_sum(dy, ctx.mg[1] if ctx.mg is not None else None, ctx.mg is not None)
         dres = dy if ctx.needs_input_grad[3] else None
         if ctx.mg is not None:
             ctx.mg[0].add_(dw)
-            if db is not None:
-                ctx.mg[1].add_(db)
             return dx, None, None, dres
         return dx, dw.contiguous(), db, dres
 

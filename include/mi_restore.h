@@ -561,6 +561,9 @@ int mi_copy_rows(const void* src, int64_t src_rs, void* dst, int64_t dst_rs, int
  * bwd: dx[b,c,:] = dout[b,c]/N.
  * ------------------------------------------------------------------------ */
 int mi_gap_fwd(const void* x, float* out, int B, int C, int64_t N, int dtype, void* stream);
+/* bias gradient of a conv (nn.Conv2d(bias=True)): out[c] (+)= sum over batch and pixels of x[b][c][n]; fixed summation order */
+size_t mi_chan_sum_workspace(int C, int64_t N);
+int mi_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtype, int accumulate, void* ws, void* stream);
 int mi_gap_bwd(const float* dout, void* dx, int B, int C, int64_t N, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
