@@ -343,3 +343,28 @@ def test_deferred_gradient_reductions_match_the_immediate_ones(monkeypatch):
         assert ops.deferred_pending() == 0 and float(tr.flat_g.abs().sum()) > 0
     finally:
         tr.close()
+
+
+@pytest.mark.parametrize("backend", ["eager", "aot_eager"])
+def test_transformer_block_traces_through_the_custom_ops(backend):
+    """torch.compile of a TransformerBlock: while dynamo traces, the module takes the mi_restore:: custom-op door
+    (restormer._use_torch_ops), so the graph holds two opaque ops per block whose fake implementations supply the shapes -
+    `aot_eager` also traces the backward through register_autograd.  Output and gradients equal the eager run bit for bit."""
+    m = M()
+    torch._dynamo.reset()
+    torch.manual_seed(11)
+    blk = m.TransformerBlock(48, 1, 2.66, False, "WithBias").to(DEV)
+    x = seeded_input((2, 48, 16, 64), 93).to(DEV).to(torch.bfloat16)
+
+    def run(fn):
+        for p in blk.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = fn(xx)
+        y.backward(torch.ones_like(y))
+        return [y.detach(), xx.grad] + [p.grad.clone() for p in blk.parameters()]
+    ref = run(blk)
+    got = run(torch.compile(blk, backend=backend, fullgraph=True))
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
