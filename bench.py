@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 Restormer / 8 MoCE-IR; 8 = BASELINE configs[1])")
     ap.add_argument("--patch", type=int, default=0, help="patch size (default 256 Restormer / 128 MoCE-IR)")
     ap.add_argument("--graph", type=int, default=0,
-                    help="1: replay the step as one HIP graph (N=1, Restormer only).  Off by default: the eager step is not "
-                         "launch-bound, and the graph's private pool doubles peak memory")
+                    help="1: replay the step as one HIP graph (N=1; Restormer, or MoCE-IR whose small-batch dispatch keeps the "
+                         "segment sizes on the device).  Off by default for Restormer: the eager step is not launch-bound, and "
+                         "the graph's private pool doubles peak memory")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + sharded AdamW + all-gather instead of the overlapped bucketed all-reduce (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,6 +214,9 @@ def main():
             return AdaIR(**configs.ADAIR_BASE).to(dev).train()
         return m.Restormer(**configs.RESTORMER_BASE).to(dev)
 
+    if args.graph == 1:
+        os.environ["MI_DEFER_MB"] = "0"     # the deferred reductions stage their job table from pinned host memory: not for capture
+        os.environ.setdefault("MI_MOCE_DISPATCH", "capacity")   # MoCE-IR: segment sizes stay on the device (no .tolist())
     model = build_model()
     n_params = sum(p.numel() for p in model.parameters())
     trainer = FlatTrainer(model, lr=2e-4, shard_optimizer=args.shard_optimizer)
@@ -224,7 +228,7 @@ def main():
     clean = clean32.to(dev).to(act)
     noisy = noisy32.to(dev).to(act)
 
-    use_graph = args.graph == 1 and world == 1 and args.model == "restormer"
+    use_graph = args.graph == 1 and world == 1 and args.model in ("restormer", "moce")
     step, loss_buf = make_step(model, trainer, noisy, clean, use_dev_scalars=use_graph, moce=moce)
 
     def run_eager(n):
@@ -235,9 +239,18 @@ def main():
 
     graph = None
     if use_graph:
-        # a few eager steps first (allocator warm-up), then capture ONE full step and replay it
-        run_eager(2)
+        # a few eager steps first (allocator warm-up) - on a SIDE stream, as whole-network capture wants: parameters that
+        # receive their gradient through autograd's AccumulateGrad (MoCE-IR's router and embedding MLP) bind that node to the
+        # stream of their first backward, and a node bound to the legacy default stream takes the capture down - then capture
+        # ONE full step and replay it
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run_eager(2)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for p_ in model.parameters():
+            p_.grad = None
         try:
             graph = torch.cuda.CUDAGraph()
             trainer.set_step_scalars(trainer.step_count + 1)

@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteBwdArgs a) {
   const float sigma = 1.0f / (float)E;
   const float daux = (a.training && a.daux) ? a.daux[0] : 0.f;
   for (int b = t; b < B; b += 256) {
-    float n[ROUTE_MAX_E], l[ROUTE_MAX_E], ds[ROUTE_MAX_E];
+    // per-sample work vectors in LDS, not in registers: they are indexed by the top-k indices, and as local arrays they lived
+    // in scratch memory - the one scratch user of the MoCE step, and what took HIP-graph capture of the step down at instantiation
+    float* const n = rsm + (3 * B + b) * E;
+    float* const l = rsm + (4 * B + b) * E;
+    float* const ds = rsm + (5 * B + b) * E;
     float mx = -INFINITY, mc = -INFINITY;
     for (int e = 0; e < E; ++e) {
       l[e] = a.logits[b * E + e]; n[e] = l[e] + a.noise[b * E + e] * sigma;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteBwdArgs a) {
     __syncthreads();
     for (int b = t; b < B; b += 256) {
       const int kth = (int)a.topk_idx[(int64_t)b * k + (k - 1)];
-      float dcv[ROUTE_MAX_E];
+      float* const dcv = rsm + (3 * B + b) * E;          // (the n vector is dead by now)
       float dot = 0.f, dthr = 0.f;
       for (int e = 0; e < E; ++e) {
         dcv[e] = s_g[0][e] * (a.complexity ? a.complexity[e] : 1.f);          // d L_imp / d softmax(clean)[b][e]
@@ -386,12 +390,12 @@ extern "C" int mi_moe_route_bwd(const float* pooled, const float* freq, const fl
   MI_CHECK_ARG(!drow || row_of, "moe_route_bwd: drow needs row_of");
   MI_CHECK_ARG(pooled && freq && wg && wf && noise && logits && topk_idx && dpooled && dfreq && dwg && dwf,
                "moe_route_bwd: null pointer");
-  MI_CHECK_ARG(B > 0 && C > 0 && F > 0 && E >= 2 && E <= ROUTE_MAX_E && k >= 1 && k <= E && B * E <= ROUTE_MAX_BE,
-               "moe_route_bwd: bad shape");
+  MI_CHECK_ARG(B > 0 && C > 0 && F > 0 && E >= 2 && E <= ROUTE_MAX_E && k >= 1 && k <= E && B * E <= ROUTE_MAX_BE * 3 / 4,
+               "moe_route_bwd: bad shape (six [B][E] fp32 vectors must fit the 160 KB of LDS: B * E <= %d)", ROUTE_MAX_BE * 3 / 4);
   RouteBwdArgs a{pooled, freq, wg, wf, noise, complexity, logits, topk_idx, dgates, drow, row_of, daux, dpooled, dfreq, dwg, dwf,
                  B, C, F, E, k, training};
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = 3 * (size_t)B * E * sizeof(float);
+  const size_t lds = 6 * (size_t)B * E * sizeof(float);   // DL, Pc, Pl + the three per-sample work vectors
   if (lds > 48 * 1024)
     MI_CHECK_HIP(hipFuncSetAttribute((const void*)route_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps(st, K_MOE_ROUTE, 4.0 * ((double)B * (C + F) * 2 + (double)E * (C + F) * 2), 4.0 * B * E * (C + F));

@@ -225,6 +225,13 @@ def _w2(w: Tensor) -> Tensor:
     return w.reshape(w.shape[0], -1)
 
 
+def _segment_rows(dev_offsets: Tensor, E: int, R: int) -> Tensor:
+    """[E, R] int64: row (offsets[e] + i) of the stitched buffers for i = 0..R-1, clamped to the last row - the device-side
+    replacement of the host slices ``rows[o:o + n]`` when the segment sizes are not read back (capacity mode)."""
+    ar = torch.arange(R, device=dev_offsets.device, dtype=torch.int64)
+    return (dev_offsets[:E].to(torch.int64).unsqueeze(1) + ar.unsqueeze(0)).clamp_(max=R - 1).contiguous()
+
+
 class _ExpertsInFn(torch.autograd.Function):
     """First step of every expert at once (:552-555): a_e = proj[0]_e(x[rows of e]), g_e = proj[1]_e(shared[rows of e]) for all
     E experts in ONE grouped launch (csrc/grouped.hip) that reads the segment sizes / starts from the router's device tables.
@@ -232,13 +239,16 @@ class _ExpertsInFn(torch.autograd.Function):
     stitched gradient buffers); the weight gradients are per-expert Grams."""
 
     @staticmethod
-    def forward(ctx, xrows, srows, counts, dev_counts, dev_offsets, *ws):
+    def forward(ctx, xrows, srows, counts, cap, dev_counts, dev_offsets, *ws):
         E = len(counts)
         w0, w1 = ws[:E], ws[E:]
         R, Cc, H, W = xrows.shape
         N = H * W
-        outs_a = [torch.empty((n, w0[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
-        outs_g = [torch.empty((n, w1[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
+        # cap (capacity mode): counts[e] is every expert's buffer CAPACITY (all rows); the kernels write the true count of rows,
+        # the rest stays zero so that the bodies see finite inputs and contribute nothing
+        new = torch.zeros if cap else torch.empty
+        outs_a = [new((n, w0[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
+        outs_g = [new((n, w1[e].shape[0], H, W), dtype=xrows.dtype, device=xrows.device) for e, n in enumerate(counts)]
         probs = []
         for e, n in enumerate(counts):
             if n:
@@ -246,7 +256,7 @@ class _ExpertsInFn(torch.autograd.Function):
                 probs.append(dict(x=srows, w=_w2(w1[e]), y=outs_g[e], m=w1[e].shape[0], k=Cc, expert=e, y_local=True))
         if probs:
             ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, N, xrows.dtype)
-        ctx.counts = counts
+        ctx.counts, ctx.cap = counts, cap
         ctx.save_for_backward(xrows, srows, dev_counts, dev_offsets, *ws)
         ctx.mg = [getattr(w, "main_grad", None) for w in ws]
         return tuple(outs_a) + tuple(outs_g)
@@ -274,6 +284,7 @@ class _ExpertsInFn(torch.autograd.Function):
             ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, xrows.dtype)
         dws = []
         o = 0
+        idx = _segment_rows(dev_offsets, E, R) if ctx.cap else None
         for which, (d_list, src) in enumerate(((da, xrows), (dg, srows))):
             o = 0
             for e, n in enumerate(counts):
@@ -281,13 +292,18 @@ class _ExpertsInFn(torch.autograd.Function):
                 if not n:
                     dws.append(None)
                     continue
-                g = ops.gram(d_list[e], src[o:o + n], 1, True)[0].reshape(w.shape)
-                if ctx.mg[which * E + e] is not None:
-                    ctx.mg[which * E + e].add_(g)
+                # the expert's rows of the stitched source: a host slice, or (capacity mode) a gather by the device-side
+                # segment start - rows past the segment meet zero gradient rows
+                rows_e = ops.rows_gather(src, idx[e]) if ctx.cap else src[o:o + n]
+                mg = ctx.mg[which * E + e]
+                if mg is not None:                       # straight into the trainer's gradient slot (deferrable final sum)
+                    ops.gram(d_list[e], rows_e, 1, True, out=mg, accumulate=True)
                     g = None
+                else:
+                    g = ops.gram(d_list[e], rows_e, 1, True)[0].reshape(w.shape)
                 dws.append(g)
                 o += n
-        return (dx, ds, None, None, None) + tuple(dws)
+        return (dx, ds, None, None, None, None) + tuple(dws)
 
 
 class _ExpertsOutFn(torch.autograd.Function):
@@ -296,7 +312,7 @@ class _ExpertsOutFn(torch.autograd.Function):
     gradients dt_e = proj[2]_e^T dout[rows of e] of all experts are one grouped launch too."""
 
     @staticmethod
-    def forward(ctx, xrows, counts, dev_counts, dev_offsets, *tw):
+    def forward(ctx, xrows, counts, cap, dev_counts, dev_offsets, *tw):
         E = len(counts)
         ts, ws = tw[:E], tw[E:]
         out = torch.empty_like(xrows)
@@ -305,7 +321,7 @@ class _ExpertsOutFn(torch.autograd.Function):
                  for e, n in enumerate(counts) if n]
         if probs:
             ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, xrows.dtype)
-        ctx.counts = counts
+        ctx.counts, ctx.cap = counts, cap
         ctx.save_for_backward(dev_counts, dev_offsets, *[t for t in ts if t is not None], *ws)
         ctx.present = [t is not None for t in ts]
         ctx.mg = [getattr(w, "main_grad", None) for w in ws]
@@ -321,24 +337,27 @@ class _ExpertsOutFn(torch.autograd.Function):
         ts = [next(it) if pr else None for pr in ctx.present]
         ws = saved[nt:]
         R, Cc, H, W = dout.shape
-        dts = [torch.empty_like(t) if t is not None else None for t in ts]
+        dts = [(torch.zeros_like(t) if ctx.cap else torch.empty_like(t)) if t is not None else None for t in ts]
         probs = [dict(x=dout, w=_w2(ws[e]), transposed=True, y=dts[e], m=ws[e].shape[1], k=Cc, expert=e, y_local=True)
                  for e, n in enumerate(ctx.counts) if n]
         if probs:
             ops.grouped_pw_gemm(probs, dev_counts, dev_offsets, R, H * W, dout.dtype)
         dws = []
         o = 0
+        idx = _segment_rows(dev_offsets, E, R) if ctx.cap else None
         for e, n in enumerate(ctx.counts):
             if not n:
                 dws.append(None)
                 continue
-            g = ops.gram(dout[o:o + n], ts[e], 1, True)[0].reshape(ws[e].shape)
+            rows_e = ops.rows_gather(dout, idx[e]) if ctx.cap else dout[o:o + n]      # (rows past the segment meet ts[e] rows that are zero)
             if ctx.mg[e] is not None:
-                ctx.mg[e].add_(g)
+                ops.gram(rows_e, ts[e], 1, True, out=ctx.mg[e], accumulate=True)
                 g = None
+            else:
+                g = ops.gram(rows_e, ts[e], 1, True)[0].reshape(ws[e].shape)
             dws.append(g)
             o += n
-        return (dout, None, None, None) + tuple(dts) + tuple(dws)
+        return (dout, None, None, None, None) + tuple(dts) + tuple(dws)
 
 
 # ======================================================================================
@@ -455,7 +474,7 @@ class ModExpert(nn.Module):
         n = x.shape[0]
         cnt = torch.tensor([n], dtype=torch.int32, device=x.device)
         off = torch.zeros(1, dtype=torch.int32, device=x.device)
-        return _apply(_ExpertsOutFn, x, (n,), cnt, off, t, self.proj[2].weight)      # proj[2](t) + x in one GEMM epilogue
+        return _apply(_ExpertsOutFn, x, (n,), False, cnt, off, t, self.proj[2].weight)      # proj[2](t) + x in one GEMM epilogue
 
     def forward(self, x, shared):
         if x.shape[0] == 0:
@@ -518,6 +537,8 @@ def _ladder(kind, base, n, dim=None):
 class AdapterLayer(nn.Module):
     """E experts of growing rank / patch / kernel behind the noisy top-k router, then a 1x1 projection (:584-681)."""
 
+    CAPACITY_ROWS = 32                  # B * k up to which every expert runs over all rows (capacity mode, no host read-back)
+
     def __init__(self, dim: int, rank: int, num_experts: int = 4, top_k: int = 2, expert_layer: nn.Module = FFTAttention,
                  stage_depth: int = 1, depth_type: str = "lin", rank_type: str = "constant", freq_dim: int = 128,
                  with_complexity: bool = False, complexity_scale: str = "min"):
@@ -527,6 +548,7 @@ class AdapterLayer(nn.Module):
         self.top_k = top_k
         self.noise_eps = 1e-2
         self.num_experts = num_experts
+        self.dispatch = "ragged"        # "ragged" | "capacity" | "auto" (see forward); MI_MOCE_DISPATCH overrides
         E = num_experts
         depths = _ladder(depth_type, stage_depth, E)
         if depths is None:
@@ -548,18 +570,26 @@ class AdapterLayer(nn.Module):
     def forward(self, x, freq_emb, shared):
         gates, idx, vals, aux, row_gate, tb = self.routing.route(x, freq_emb)
         self.loss = aux[0] if self.training else 0
-        # E segment sizes: only the experts' BODIES (FFTAttention: ragged tensors) still need them on the host; the three 1x1
-        # projections of all experts are grouped launches that read the sizes from the router's device tables
-        counts = tuple(tb.counts.tolist())
-        E = len(counts)
+        # Segment sizes.  Ragged mode (default): the E sizes come to the host (as the reference's .tolist(), :88) so that the
+        # bodies run on exactly their rows.  Capacity mode (dispatch = "capacity", or "auto" with B * k <= CAPACITY_ROWS):
+        # NOTHING is read back - every expert's buffers hold all B * k rows, the grouped launches write / read the true number
+        # of rows (device tables) and the bodies run over zero rows beyond it; static shapes, no host sync, so the whole step
+        # can be captured in a HIP graph (bench.py --model moce --graph 1).  Measured at bs 8: the E-fold body work
+        # and the per-expert row gathers of the weight gradients cost more than the 20 small read-backs they remove, and the
+        # step is bound by the GPU's ~15 us per dependent tiny kernel either way - hence not the default.
+        E = self.num_experts
+        R = x.shape[0] * self.top_k
+        mode = ops.env("MI_MOCE_DISPATCH") or self.dispatch
+        cap = mode == "capacity" or (mode == "auto" and R <= self.CAPACITY_ROWS)
+        counts = (R,) * E if cap else tuple(tb.counts.tolist())
         xrows = _RowsGatherFn.apply(x.contiguous(), tb.perm)
         srows = _RowsGatherFn.apply(shared.contiguous(), tb.perm)
         mods = [ex[0] for ex in self.experts]
-        ag = _apply(_ExpertsInFn, xrows, srows, counts, tb.counts, tb.offsets, *[m_.proj[0].weight for m_ in mods],
+        ag = _apply(_ExpertsInFn, xrows, srows, counts, cap, tb.counts, tb.offsets, *[m_.proj[0].weight for m_ in mods],
                     *[m_.proj[1].weight for m_ in mods])
         inner: List[Optional[Tensor]] = [
             _apply(_EwiseFn, mods[e].body(ag[e]), ag[E + e], 1) if counts[e] else None for e in range(E)]
-        rows_out = _apply(_ExpertsOutFn, xrows, counts, tb.counts, tb.offsets, *inner, *[m_.proj[2].weight for m_ in mods])
+        rows_out = _apply(_ExpertsOutFn, xrows, counts, cap, tb.counts, tb.offsets, *inner, *[m_.proj[2].weight for m_ in mods])
         out = _RowsCombineFn.apply(rows_out, row_gate, tb.perm, x.shape[0])     # gate multiply + fp32 scatter-add (:116-124)
         return _c1(out.to(x.dtype), self.proj_out)
 

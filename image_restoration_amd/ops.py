@@ -156,15 +156,17 @@ def dwconv_gate_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], want_y: bool =
     return y, g
 
 
-def dwconv_bwd(dy: Tensor, x: Tensor, w: Tensor, has_bias: bool):
+def dwconv_bwd(dy: Tensor, x: Tensor, w: Tensor, has_bias: bool, grads: Optional[Sequence[Optional[Tensor]]] = None):
+    """grads = (dw, db) fp32 buffers to ACCUMULATE into (a trainer's main_grad slots); None: fresh tensors are returned."""
     _gpu(dy, x, w)
     B, Cc, H, W = x.shape
     ks = w.shape[-1]
     dx = torch.empty_like(x)
-    dw = torch.empty_like(w)
-    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_bias else None
+    acc = grads is not None
+    dw = _f32(grads[0], "depthwise weight gradient") if acc else torch.empty_like(w)
+    db = (_f32(grads[1], "depthwise bias gradient") if acc else torch.empty(Cc, dtype=torch.float32, device=x.device)) if has_bias else None
     ws = _ws(L.lib().mi_dwconv_bwd_workspace(B, Cc, H, W, ks), x.device)
-    L.check(L.lib().mi_dwconv_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Cc, H, W, ks, 0, _dt(x), _p(ws),
+    L.check(L.lib().mi_dwconv_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, Cc, H, W, ks, 1 if acc else 0, _dt(x), _p(ws),
                                   _stream()), "dwconv_bwd")
     return dx, dw, db
 
@@ -238,21 +240,29 @@ def pw_gemm_desc(d: "L.PwDesc", device) -> None:
     L.check(L.lib().mi_pw_gemm(C.byref(d), _p(ws), _stream()), "pw_gemm")
 
 
-def gram(a: Tensor, b: Tensor, groups: int = 1, sum_batch: bool = False, want_sumsq: bool = False):
-    """G[z][i][j] = sum_n a[z][i][n] b[z][j][n] with a,b [B, groups*m, H, W] split head-major into groups."""
-    _gpu(a, b)
+def gram(a: Tensor, b: Tensor, groups: int = 1, sum_batch: bool = False, want_sumsq: bool = False,
+         out: Optional[Tensor] = None, accumulate: bool = False):
+    """G[z][i][j] = sum_n a[z][i][n] b[z][j][n] with a,b [B, groups*m, H, W] split head-major into groups.
+    out (+ accumulate): write / add the result into a caller's fp32 buffer of Z*ma*mb elements - a weight-gradient slot of the
+    trainer's flat buffer; under the trainer's deferral window the final sum then joins the one table-driven reduction launch."""
+    _gpu(a, b, out)
     B, Ca, H, W = a.shape
     Cb = b.shape[1]
     N = H * W
     ma, mb = Ca // groups, Cb // groups
     Z = groups if sum_batch else B * groups
-    out = torch.empty((Z, ma, mb), dtype=torch.float32, device=a.device)
+    if out is None:
+        if accumulate:
+            raise ValueError("gram: accumulate needs the output buffer")
+        out = torch.empty((Z, ma, mb), dtype=torch.float32, device=a.device)
+    elif out.dtype != torch.float32 or out.numel() != Z * ma * mb:
+        raise ValueError(f"gram: out must be float32 with {Z * ma * mb} elements")
     ss = torch.empty((B * groups, ma + mb), dtype=torch.float32, device=a.device) if want_sumsq else None
     d = L.GramDesc()
     d.a, d.a_bs, d.a_gs, d.ma = _p(a), Ca * N, ma * N, ma
     d.b, d.b_bs, d.b_gs, d.mb = _p(b), Cb * N, mb * N, mb
     d.n, d.batch, d.groups, d.dtype = N, B, groups, _dt(a)
-    d.sum_batch, d.accumulate = int(sum_batch), 0
+    d.sum_batch, d.accumulate = int(sum_batch), int(accumulate)
     d.out, d.out_ld, d.out_zs, d.sumsq = _p(out), mb, ma * mb, _p(ss)
     ws = _ws(L.lib().mi_gram_workspace(C.byref(d)), a.device)
     L.check(L.lib().mi_gram(C.byref(d), _p(ws), _stream()), "gram")

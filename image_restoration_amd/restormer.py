@@ -472,11 +472,8 @@ class _DwConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dx, dw, db = ops.dwconv_bwd(dy.contiguous(), x, weight, ctx.has_bias)
+        dx, dw, db = ops.dwconv_bwd(dy.contiguous(), x, weight, ctx.has_bias, ctx.mg)      # (main_grad: accumulated in place)
         if ctx.mg is not None:
-            ctx.mg[0].add_(dw)
-            if ctx.has_bias:
-                ctx.mg[1].add_(db)
             return dx, None, None
         return dx, dw, db
 
