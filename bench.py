@@ -177,6 +177,13 @@ def main():
     # MI_FORCE_COMM=1 under a one-process torchrun: the RCCL process group, the trainer's bucketed all-reduces and the barriers
     # run in a one-rank group (rehearsal of the N > 1 code path on a one-GPU box; not a measurement mode)
     dist_on = world > 1 or (os.environ.get("MI_FORCE_COMM") == "1" and "MASTER_ADDR" in os.environ)
+    # The library's freshness is decided in Python and any build runs HERE, before this process touches the GPU (and never
+    # under rocprofv3: _build refuses a stale library there) - no child process is started once the GPU is initialised.
+    from image_restoration_amd import _build
+    if rank == 0:
+        _build.build()
+    else:
+        _build.wait_fresh()
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -188,13 +195,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    import __graft_entry__ as entry
-    if dist_on:
-        # one rank runs make (the others would race it on the same object files), everybody loads the result
-        if rank == 0:
-            entry.build()
-        dist.barrier()
-    entry.build()
     import image_restoration_amd as m
     from image_restoration_amd import configs, ops
     from image_restoration_amd.trainer import FlatTrainer
@@ -215,7 +215,6 @@ def main():
         return m.Restormer(**configs.RESTORMER_BASE).to(dev)
 
     if args.graph == 1:
-        os.environ["MI_DEFER_MB"] = "0"     # the deferred reductions stage their job table from pinned host memory: not for capture
         os.environ.setdefault("MI_MOCE_DISPATCH", "capacity")   # MoCE-IR: segment sizes stay on the device (no .tolist())
     model = build_model()
     n_params = sum(p.numel() for p in model.parameters())
@@ -239,23 +238,10 @@ def main():
 
     graph = None
     if use_graph:
-        # a few eager steps first (allocator warm-up) - on a SIDE stream, as whole-network capture wants: parameters that
-        # receive their gradient through autograd's AccumulateGrad (MoCE-IR's router and embedding MLP) bind that node to the
-        # stream of their first backward, and a node bound to the legacy default stream takes the capture down - then capture
-        # ONE full step and replay it
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            run_eager(2)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for p_ in model.parameters():
-            p_.grad = None
+        # FlatTrainer.capture_step: warm-up steps on a side stream (allocator warm-up; AccumulateGrad nodes must not bind to the
+        # legacy default stream), then ONE full step captured and replayed
         try:
-            graph = torch.cuda.CUDAGraph()
-            trainer.set_step_scalars(trainer.step_count + 1)
-            with torch.cuda.graph(graph):
-                step()
+            graph = trainer.capture_step(step, warmup=2)
         except Exception as e:  # capture is an optimisation, never a requirement
             if rank == 0:
                 print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -268,9 +254,7 @@ def main():
 
     def one():
         if graph is not None:
-            trainer.set_step_scalars(trainer.step_count + 1)
-            trainer.step_count += 1
-            graph.replay()
+            trainer.replay_step(graph)
         else:
             step()
 

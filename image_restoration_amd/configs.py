@@ -14,6 +14,10 @@ MOCEIR_BASE = dict(dim=48, num_blocks=[4, 6, 6, 8], num_dec_blocks=[2, 4, 4], le
                    num_refinement_blocks=4, topk=1, num_experts=4, rank=2, with_complexity=False, depth_type="constant",
                    stage_depth=[1, 1, 1], rank_type="spread", complexity_scale="max")
 MOCEIR_S = dict(MOCEIR_BASE, dim=32)
+# the tiny widths of the whole-network golden (tools/capture_golden_moce2.py): tests and capture rehearsals
+MOCEIR_TINY = dict(dim=16, levels=4, heads=[1, 2, 4, 8], num_blocks=[1, 1, 1, 2], num_dec_blocks=[1, 1, 1],
+                   num_refinement_blocks=1, rank=2, num_experts=4, depth_type="constant", stage_depth=[1, 1, 1],
+                   rank_type="spread", topk=1, with_complexity=True, complexity_scale="max")
 # AdaIR-main/net/model.py:380-390 constructor defaults (the Restormer U-Net + three FreModules; AdaIR-main/train.py builds it bare)
 ADAIR_BASE = dict(dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66,
                   bias=False, LayerNorm_type="WithBias", decoder=True)

@@ -271,7 +271,10 @@ struct ProfScope {
 // instead of launching it; mi_deferred_flush runs all recorded jobs in ONE table-driven launch (a fixed order per job:
 // bitwise reproducible).  Nothing may read such a gradient before the flush - true for the trainer's main_grad buffers, which
 // are read by the all-reduce / optimizer only; producers whose caller reads the result at once (accumulate == 0) never defer.
-float* deferred_take(size_t nfloats);    // arena space for partials, or nullptr (inactive / arena or job table full)
+// Two recorded jobs may target the same gradient (micro-batches under no_sync(), a parameter used twice in one backward): a job
+// whose output was already recorded joins the next GENERATION, and a flush runs one launch per generation, in order.
+// While `st` is being captured into a HIP graph nothing is deferred (the flush stages its table from host memory).
+float* deferred_take(size_t nfloats, hipStream_t st);   // arena space for partials, or nullptr (inactive / full / capturing)
 bool deferred_owns(const void* p);
 // true: recorded (part must come from deferred_take); false: not recorded, the caller launches the reduction itself
 bool deferred_reduce_rows(const float* part, float* out, int64_t rows, int64_t cols, int64_t part_ld, int accumulate, float scale,

@@ -467,7 +467,7 @@ extern "C" int mi_conv3x3_wgrad(const void* dy, int64_t dy_bs, const void* x, in
   a.cols = (int64_t)cols;
   // partials: the deferred arena when the sum accumulates into a trainer's gradient buffer (one table-driven launch at the end of
   // backward runs all such sums), else the caller's workspace
-  float* part = accumulate ? deferred_take((size_t)a.S * cols) : nullptr;
+  float* part = accumulate ? deferred_take((size_t)a.S * cols, (hipStream_t)stream) : nullptr;
   if (!part) {
     MI_CHECK_ARG(ws, "conv3x3_wgrad: null workspace");
     part = (float*)ws;

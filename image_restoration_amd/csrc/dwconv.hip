@@ -686,7 +686,7 @@ static int dw_bwd_common(const void* dy_or_dg, const void* gy, const void* x, co
   int rc = MI_OK, rows = 0;
   float* part = (float*)ws;
   if (dwg && accumulate) {   // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
-    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, Cc, H, W, ks) / sizeof(float));
+    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, Cc, H, W, ks) / sizeof(float), st);
     if (arena) part = arena;
   }
   if (gate) DW_DISPATCH(T, KS, (rc = dw_gate_bwd_launch<T, KS>(a, x, part, B, dwg != nullptr, &rows, st)));
@@ -722,7 +722,7 @@ extern "C" int mi_dwconv_gate_bwd_recompute(const void* dg, const void* x, const
   int rows = 0;
   float* part = (float*)ws;
   if (dwg && accumulate) {
-    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, C2, H, W, ks) / sizeof(float));
+    float* arena = deferred_take(mi_dwconv_bwd_workspace(B, C2, H, W, ks) / sizeof(float), st);
     if (arena) part = arena;
   }
   {

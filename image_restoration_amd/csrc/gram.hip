@@ -567,7 +567,7 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
   k.part = direct ? d->out : (float*)ws;
   bool deferred = false;
   if (!direct && gram_deferrable(d)) {
-    float* arena = deferred_take(g.part_bytes / sizeof(float));
+    float* arena = deferred_take(g.part_bytes / sizeof(float), st);
     if (arena) { k.part = arena; deferred = true; }
   }
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;
@@ -630,7 +630,7 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
   k.part = direct ? d->out : (float*)ws;
   bool deferred = false;
   if (!direct && gram_deferrable(d)) {
-    float* arena = deferred_take(g.part_bytes / sizeof(float));
+    float* arena = deferred_take(g.part_bytes / sizeof(float), st);
     if (arena) { k.part = arena; deferred = true; }
   }
   k.ss_part = d->sumsq ? (float*)((char*)ws + g.part_bytes) : nullptr;

@@ -593,7 +593,7 @@ extern "C" int mi_ln_bwd(const void* dy, const void* x, const float* w, const fl
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
   if (accumulate) {          // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
-    float* arena = deferred_take(mi_ln_bwd_workspace(B, C, N) / sizeof(float));
+    float* arena = deferred_take(mi_ln_bwd_workspace(B, C, N) / sizeof(float), st);
     if (arena) part = arena;
   }
   int rows = 0, rc;

@@ -371,6 +371,9 @@ extern "C" int mi_moe_route_fwd(const float* pooled, const float* freq, const fl
                perm && perm_gate && perm_expert && row_of, "moe_route_fwd: null pointer");
   MI_CHECK_ARG(B > 0 && C > 0 && F > 0 && E >= 2 && E <= ROUTE_MAX_E && k >= 1 && k <= E && B * E <= ROUTE_MAX_BE,
                "moe_route_fwd: bad shape (B=%d C=%d F=%d E=%d k=%d)", B, C, F, E, k);
+  // the backward keeps six [B][E] vectors in LDS (the forward three): a training forward refuses what its backward could not run
+  MI_CHECK_ARG(!training || B * E <= ROUTE_MAX_BE * 3 / 4,
+               "moe_route_fwd: training batch too large for the router backward (B * E <= %d)", ROUTE_MAX_BE * 3 / 4);
   RouteArgs a{pooled, freq, wg, wf, noise, complexity, logits, gates, topk_idx, topk_val, aux, counts, offsets, perm, perm_gate,
               perm_expert, row_of, B, C, F, E, k, training};
   hipStream_t st = (hipStream_t)stream;

@@ -196,8 +196,8 @@ static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, 
   float* dwo_part = w.dwo_part;
   float* dtemp_part = w.dtemp_part;
   if (acc) {                 // parameter gradients accumulated in place: partials may wait for mi_deferred_flush (common.h)
-    float* a1 = deferred_take((size_t)B * C * C);
-    float* a2 = a1 ? deferred_take((size_t)B * hd) : nullptr;
+    float* a1 = deferred_take((size_t)B * C * C, st);
+    float* a2 = a1 ? deferred_take((size_t)B * hd, st) : nullptr;
     if (a1 && a2) { dwo_part = a1; dtemp_part = a2; }
   }
   MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, dwo_part, dtemp_part, w.wd,

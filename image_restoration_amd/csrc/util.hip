@@ -3,7 +3,9 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -131,7 +133,7 @@ struct DrJob {
   const float* part; float* tmp; float* out; float* out2;
   int64_t rows, cols, ld, split, rpg;
   int groups, accumulate; float scale;
-  int blk1, blk2;                 // first workgroup of this job in stage 1 / stage 2
+  int blk1, blk2;                 // first workgroup of this job within its generation's launch / its generation
 };
 constexpr int DR_MAX_JOBS = 2048;
 constexpr size_t DR_TABLE_BYTES = DR_MAX_JOBS * sizeof(DrJob);
@@ -147,9 +149,22 @@ static struct {
   int flip = 0;
   int nblk1 = 0, nblk2 = 0;
   size_t high = 0;                // high-water mark of the arena (diagnostics: mi_deferred_high_water)
+  std::unordered_map<const float*, int> out_gen;   // pending outputs -> generation of their latest job
+  std::vector<int> gen_blocks;    // workgroups per generation
 } g_dr;
 
-float* deferred_take(size_t nfloats) {
+static bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
+}
+
+float* deferred_take(size_t nfloats, hipStream_t st) {
+  {
+    std::lock_guard<std::mutex> lk(g_dr.mu);
+    if (!g_dr.active || !g_dr.recording) return nullptr;
+  }
+  if (stream_capturing(st)) return nullptr;              // a captured step sums at once: the flush is not capturable
   std::lock_guard<std::mutex> lk(g_dr.mu);
   if (!g_dr.active || !g_dr.recording || g_dr.jobs.size() + 1 >= (size_t)DR_MAX_JOBS) return nullptr;
   const size_t need = align_up(nfloats * sizeof(float), 256);
@@ -173,8 +188,21 @@ bool deferred_reduce_rows(const float* part, float* out, int64_t rows, int64_t c
   j.groups = 1; j.rpg = rows; j.tmp = nullptr;
   std::lock_guard<std::mutex> lk(g_dr.mu);
   if (!g_dr.active || g_dr.jobs.size() >= (size_t)DR_MAX_JOBS) return false;
-  j.blk1 = g_dr.nblk1; j.blk2 = 0;
-  g_dr.nblk1 += cdiv(cols, 256);
+  // generation: one past the latest pending job that writes the same gradient (a plain read-modify-write per job, and
+  // workgroups of one launch run concurrently: same-output jobs must be separate, ordered launches)
+  int gen = 0;
+  for (const float* o : {(const float*)out, (const float*)out2}) {
+    if (!o) continue;
+    auto it = g_dr.out_gen.find(o);
+    if (it != g_dr.out_gen.end() && it->second + 1 > gen) gen = it->second + 1;
+  }
+  g_dr.out_gen[out] = gen;
+  if (out2) g_dr.out_gen[out2] = gen;
+  if ((int)g_dr.gen_blocks.size() <= gen) g_dr.gen_blocks.resize(gen + 1, 0);
+  j.blk2 = gen;
+  j.blk1 = g_dr.gen_blocks[gen];
+  g_dr.gen_blocks[gen] += (int)cdiv(cols, 256);
+  g_dr.nblk1 += (int)cdiv(cols, 256);
   g_dr.jobs.push_back(j);
   return true;
 }
@@ -331,6 +359,7 @@ extern "C" int mi_deferred_begin(void* arena, size_t bytes) {
     }
   mi::g_dr.arena = (char*)arena; mi::g_dr.bytes = bytes; mi::g_dr.off = mi::DR_TABLE_BYTES;
   mi::g_dr.jobs.clear(); mi::g_dr.nblk1 = mi::g_dr.nblk2 = 0;
+  mi::g_dr.out_gen.clear(); mi::g_dr.gen_blocks.clear();
   mi::g_dr.active = true;
   mi::g_dr.recording = false;
   return MI_OK;
@@ -353,7 +382,15 @@ extern "C" int mi_deferred_flush(void* stream) {
   hipStream_t st = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(mi::g_dr.mu);
   if (!mi::g_dr.active || mi::g_dr.jobs.empty()) { if (mi::g_dr.active) mi::g_dr.off = mi::DR_TABLE_BYTES; return MI_OK; }
+  if (mi::stream_capturing(st)) {
+    mi::set_error("deferred_flush: %d recorded gradient sums are pending and the stream is being captured into a HIP graph; flush "
+                  "before the capture begins (FlatTrainer.zero_grad / reduce_gradients do)", (int)mi::g_dr.jobs.size());
+    return MI_ERR_ARG;
+  }
   const int n = (int)mi::g_dr.jobs.size();
+  const int ngen = (int)mi::g_dr.gen_blocks.size();
+  if (ngen > 1)                                           // the table goes out grouped by generation (stable: blk1 stays sorted)
+    std::stable_sort(mi::g_dr.jobs.begin(), mi::g_dr.jobs.end(), [](const mi::DrJob& x, const mi::DrJob& y) { return x.blk2 < y.blk2; });
   // two pinned staging tables used alternately: the one taken now was last copied from two flushes ago
   const int f = mi::g_dr.flip;
   mi::g_dr.flip ^= 1;
@@ -363,12 +400,19 @@ extern "C" int mi_deferred_flush(void* stream) {
   MI_CHECK_HIP(hipEventRecord(mi::g_dr.copied[f], st));
   double bytes = 0;
   for (const auto& j : mi::g_dr.jobs) bytes += 4.0 * (double)(j.rows + 1) * j.cols;
-  {
-    ProfScope ps(st, K_REDUCE_ROWS, bytes, bytes / 4.0);
-    hipLaunchKernelGGL(mi::deferred_reduce_kernel, dim3(mi::g_dr.nblk1), dim3(256), 0, st, (const mi::DrJob*)mi::g_dr.arena, n);
-    MI_LAUNCH_CHECK();
+  for (int g = 0, j0 = 0; g < ngen; ++g) {                // one launch per generation, in order
+    int j1 = j0;
+    while (j1 < n && mi::g_dr.jobs[j1].blk2 == g) ++j1;
+    if (j1 > j0) {
+      ProfScope ps(st, K_REDUCE_ROWS, bytes / ngen, bytes / 4.0 / ngen);
+      hipLaunchKernelGGL(mi::deferred_reduce_kernel, dim3(mi::g_dr.gen_blocks[g]), dim3(256), 0, st,
+                         (const mi::DrJob*)mi::g_dr.arena + j0, j1 - j0);
+      MI_LAUNCH_CHECK();
+    }
+    j0 = j1;
   }
   mi::g_dr.jobs.clear(); mi::g_dr.nblk1 = mi::g_dr.nblk2 = 0; mi::g_dr.off = mi::DR_TABLE_BYTES;
+  mi::g_dr.out_gen.clear(); mi::g_dr.gen_blocks.clear();
   return MI_OK;
 }
 extern "C" int mi_deferred_end(void) {

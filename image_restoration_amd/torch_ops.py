@@ -322,7 +322,10 @@ OPS = {"layernorm": (layernorm_fwd, layernorm_bwd), "mdta": (mdta_fwd, mdta_bwd)
 def _need(x: Tensor, params) -> bool:
     need = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
     _MAIN_GRADS.pop("next", None)
-    if need:
+    # Under torch.compile the hand-off below would run at TRACE time and the in-place accumulation into main_grad would be a
+    # side effect the graph cannot see (the bwd ops declare mutates_args=()): compiled steps return their parameter
+    # gradients as outputs instead (accumulate=False; FlatTrainer._fold_autograd_grads adds .grad into main_grad).
+    if need and not torch.compiler.is_compiling():
         mg = [None if p is None else getattr(p, "main_grad", None) for p in params]
         if any(p is not None for p in params) and all(g is not None for p, g in zip(params, mg) if p is not None):
             _MAIN_GRADS["next"] = mg

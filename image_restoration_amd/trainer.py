@@ -302,9 +302,7 @@ class FlatTrainer:
 
     def reduce_gradients(self) -> None:
         """Call after backward: folds autograd-delivered grads, all-reduces whatever is not yet in flight, waits."""
-        self.flush_deferred()
-        if self._defer_token is not None:
-            ops.deferred_record(False)
+        self.grads_ready()
         if not self._comm:
             self._fold_autograd_grads(self.model)
             return
@@ -333,7 +331,48 @@ class FlatTrainer:
                             dtype=torch.float32)
         self.dev_scalars.copy_(vals, non_blocking=True)
 
+    def grads_ready(self) -> None:
+        """Make ``flat_g`` / every ``main_grad`` final: run the parameter-gradient sums the backward recorded (they are deferred
+        into one launch, ops.deferred_*) and stop recording.  reduce_gradients() and optimizer_step() call it; anything else that
+        reads gradients between backward and the optimizer step (clipping by norm, logging) must call it first."""
+        if self._defer_token is not None:
+            ops.deferred_flush()
+            ops.deferred_record(False)
+
+    def capture_step(self, step_fn, warmup: int = 2):
+        """Capture ``step_fn`` (a whole training step ending in ``optimizer_step(use_dev_scalars=True)``) into a HIP graph and
+        return it; ``replay_step(graph)`` runs it.  The warm-up steps run on a SIDE stream: a parameter whose gradient arrives
+        through autograd's AccumulateGrad (MoCE-IR's router gates, the embedding MLP) binds that node to the stream of its
+        first backward, and a node bound to the legacy default stream takes hipStreamEndCapture down.  Pending deferred sums
+        are flushed first; while the capture runs nothing is deferred (the library sums at once on a capturing stream)."""
+        assert self.flat_p.is_cuda, "capture_step needs the parameters on the GPU"
+        self.grads_ready()
+        side = torch.cuda.Stream(device=self.flat_p.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.set_step_scalars(self.step_count + 1)
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.grads_ready()
+        for p in self.params:
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        self.set_step_scalars(self.step_count + 1)
+        with torch.cuda.graph(graph):
+            step_fn()
+        return graph
+
+    def replay_step(self, graph) -> None:
+        """One more step of a captured graph: refresh the device-side {lr, bias corrections}, then replay."""
+        self.set_step_scalars(self.step_count + 1)
+        self.step_count += 1
+        ops.bump_weights_epoch()
+        graph.replay()
+
     def optimizer_step(self, use_dev_scalars: bool = False) -> None:
+        self.grads_ready()            # a loop that skips reduce_gradients() (one GPU) must not step on incomplete gradients
         self.step_count += 1
         ops.bump_weights_epoch()      # the fused AdamW kernel writes the parameters without bumping any version counter
         scale = 1.0 / self.world

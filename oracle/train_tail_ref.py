@@ -3,9 +3,10 @@ schedule and the frequency-domain loss.  Only tests/ may import this module.
 
 warmup_cosine_lrs is pinned against the imported reference: tests/golden/schedule_lr.npz was written by
 tools/capture_golden_f3.py from MoCE-IR-main/src/utils/schedulers.py:239-346 (tests/test_train_tail.py).
-fft_loss: PARITY UNPINNED - MoCE-IR-main/src/utils/loss_utils.py imports torchvision and pytorch_msssim at module level,
-neither is installed in the build container, so the reference's FFTLoss (loss_utils.py:139-152) could not be run; the
-restatement follows its seven lines and is checked only against an independent fp64 evaluation in the test."""
+fft_loss is pinned too (round 4): tests/golden/fft_loss.npz holds losses and prediction gradients produced by the reference's own
+FFTLoss class (MoCE-IR-main/src/utils/loss_utils.py:139-152), imported by tools/capture_golden_f3.py with empty stand-ins for
+the module-level torchvision / pytorch_msssim imports that class never touches; tests/test_train_tail.py checks this
+restatement (and the product's FFTLoss on the GPU) against it, besides the independent dense-DFT evaluation."""
 from __future__ import annotations
 
 import math
