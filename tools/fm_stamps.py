@@ -3,7 +3,7 @@ stamps around the phases; csrc/fused_mdta.hip) and prints each phase's share of 
 serialise the waves' own overlap.  python tools/fm_stamps.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MI_FM_DEBUG"] = str(0x1000)
+os.environ["MI_FM_DEBUG"] = str(0x1000 | int(os.environ.get("FM_ABL", "0")))
 import torch
 import image_restoration_amd as m
 from image_restoration_amd import ops
@@ -22,7 +22,8 @@ for C, heads, H, W in ((48, 1, 256, 256), (96, 2, 128, 128), (96, 1, 256, 256)):
     st = mean.flatten()[: 256 * 8 * 8].view(-1, 8)
     st = st[st[:, 6] > 0]
     tot = st[:, 6].mean().item()
-    names = ["stage+barriers", "LayerNorm", "GEMM1", "barrier wait", "Gram", "conv"]
+    names = (["top barrier+stage", "LayerNorm", "barrier", "GEMM1", "barrier", "wave-local conv/Gram/stores"] if os.environ.get("MI_FM_CFG", "") == ""
+             and C == 48 else ["stage+barriers", "LayerNorm", "GEMM1", "barrier wait", "Gram", "conv"])
     parts = ", ".join(f"{n} {100 * st[:, i].mean().item() / tot:4.1f}%" for i, n in enumerate(names))
     acc = sum(st[:, i].mean().item() for i in range(6))
     print(f"C={C} heads={heads} {H}x{W} bs={B}: wave lifetime {tot:9.0f} cycles for {st[:, 7].mean().item():.0f} tiles = "
