@@ -61,4 +61,66 @@ __device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) { return __bu
 __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 }  // namespace fz
+
+// ---- tile staging shared by the persistent fused kernels (fused_mdta.hip, fused_gdfn.hip): K supplies C, NT, HR, VPR, TW, BODY,
+// HPXP, NE, NBV, NBN, NEN, PLANE
+using namespace fz;
+// The next tile's raw x (tile + halo) travels global -> registers while the current tile's v chunks are computed, and
+// registers -> LDS once the current tile is done: the HBM latency of the staging hides behind compute.
+template <typename K> struct FmStage { u32x4 raw[K::NBN]; u16 rawe[K::NEN]; };
+
+template <typename K>
+__device__ __forceinline__ void fm_stage_load(FmStage<K>& st, const bf16* xb, int tt, int x0, int y0, int H, int W, int64_t HW) {
+#pragma unroll
+  for (int n = 0; n < K::NBN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+    const int Y = y0 - 1 + r;
+    st.raw[n] = (u32x4){0u, 0u, 0u, 0u};
+    if (idx < K::NBV && Y >= 0 && Y < H)
+      st.raw[n] = *reinterpret_cast<const u32x4*>(xb + (int64_t)cc * HW + (int64_t)Y * W + x0 + 8 * u);
+  }
+#pragma unroll
+  for (int n = 0; n < K::NEN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / K::NE, k = idx - cc * K::NE;
+    st.rawe[n] = 0;
+    if (idx < K::C * K::NE && k < 2 * K::HR) {
+      const int side = k >= K::HR ? 1 : 0, r = k - side * K::HR;
+      const int Y = y0 - 1 + r, X = side ? x0 + K::TW : x0 - 1;
+      if (Y >= 0 && Y < H && X >= 0 && X < W)
+        st.rawe[n] = reinterpret_cast<const u16*>(xb)[(int64_t)cc * HW + (int64_t)Y * W + X];
+    }
+  }
+}
+template <typename K>
+__device__ __forceinline__ void fm_stage_store(const FmStage<K>& st, bf16* S, int tt) {
+#pragma unroll
+  for (int n = 0; n < K::NBN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / (K::HR * K::VPR), rem = idx - cc * (K::HR * K::VPR), r = rem / K::VPR, u = rem % K::VPR;
+    if (idx < K::NBV) *reinterpret_cast<u32x4*>(&S[cc * K::PLANE + r * K::TW + 8 * u]) = st.raw[n];
+  }
+#pragma unroll
+  for (int n = 0; n < K::NEN; ++n) {
+    const int idx = tt + K::NT * n;
+    const int cc = idx / K::NE, k = idx - cc * K::NE;
+    if (idx < K::C * K::NE) reinterpret_cast<u16*>(S)[cc * K::PLANE + K::BODY + k] = st.rawe[n];
+  }
+}
+
+// Diagnostic build path (MI_FM_DEBUG & 0x1000): shader-clock stamps around the phases, summed per wave and written as floats to
+// the `mean` buffer ([workgroup][wave][8]: stage + barrier, LayerNorm, GEMM1, barrier wait, Gram, conv, whole kernel, tiles).
+// Stamps serialise what the real kernel overlaps: read the SHARES, never the run time of such a run.
+__device__ __forceinline__ unsigned long long fm_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+
+// byte offset of 4-channel group `g4` (0..3) of pixel record r: the two 16-byte halves of a record are swapped on every other
+// group of four records, which takes the GEMM1 stores (16 lanes = 16 consecutive records, 8 bytes each) from 4-way to 2-way bank
+// conflicts and leaves the conv's 16-byte operand reads conflict-free
+__device__ __forceinline__ int fm4_rec(int r, int g4) { return r * 32 + ((((g4 >> 1) ^ (r >> 2)) & 1) << 4) + ((g4 & 1) << 3); }
+
 }  // namespace mi
