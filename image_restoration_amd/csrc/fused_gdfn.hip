@@ -1055,7 +1055,11 @@ __global__ __launch_bounds__(512, 2) void fg4_fwd_kernel(Fg4Args a) {
         }
         wave_sync();                                      // the patch is free for the next group
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's weight pieces for the next phase have landed (and its stores left)
+      // this wave's weight pieces for the next phase have landed; the SAVE form's 3 GP stores of this phase, the youngest vector-memory
+      // operations of the wave, stay in flight (vmcnt counts loads and stores together, in issue order)
+      // (only when every pair chunk of the group has a live channel: a store whose lanes are all off may not be issued at all)
+      if (SAVE && (gi * GP + GP - 1) * 16 < a.hidden) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       FG4_STAMP(5);
       __syncthreads();
       FG4_STAMP(4);
@@ -1265,9 +1269,14 @@ extern "C" int mi_gdfn_fused_fwd(const mi_gdfn_fused_shape* s, const void* pack,
   const FgSel f = fg_select(s->C, s->H);
   const FgPackLayout l = fg_pack_layout(s->C, s->hidden, f.pc);
   hipStream_t st = (hipStream_t)stream;
-  if (!fg_use_v2())                                       // fourth form (depthwise conv on the matrix cores); MI_FG_CFG=v2...: the forms above
-    return s->C == 48 ? fg4_launch<48, false>(s, pack, y, out, mean, rstd, nullptr, nullptr, st)
-                      : fg4_launch<96, false>(s, pack, y, out, mean, rstd, nullptr, nullptr, st);
+  // fourth form (depthwise conv on the matrix cores): default at C = 48 (607 vs 666 us at 256^2, bs 32); at C = 96 its 8-wave
+  // form spills (xa + output accumulators + operand pipeline > 256 registers) and loses to the form above: MI_FG_CFG=v4 forces it,
+  // MI_FG_CFG=v2... keeps the forms above everywhere
+  { const char* e = MI_ENV(MI_FG_CFG);
+    const bool v4 = e && strstr(e, "v4");
+    if (!fg_use_v2() && (s->C == 48 || v4))
+      return s->C == 48 ? fg4_launch<48, false>(s, pack, y, out, mean, rstd, nullptr, nullptr, st)
+                        : fg4_launch<96, false>(s, pack, y, out, mean, rstd, nullptr, nullptr, st); }
 #define FG_CASE(CC, TH, TW, PC, NW) \
   if (s->C == CC && f.th == TH && f.tw == TW && f.pc == PC && f.nw == NW) \
     return fg_launch<CC, TH, TW, PC, NW>(s, l, pack, y, out, mean, rstd, st)
@@ -1298,8 +1307,11 @@ int fused_gdfn_fwd_save(const mi_gdfn_fused_shape* s, const void* pack, const vo
   MI_CHECK_ARG(pack && y && out && mean && rstd && h0 && g, "gdfn_fused_fwd_train: null pointer");
   MI_CHECK_ARG(aligned16(pack) && aligned16(y) && aligned16(out) && aligned16(h0) && aligned16(g),
                "gdfn_fused_fwd_train: pointers must be 16-byte aligned");
-  if (!fg_use_v2())
-    return s->C == 48 ? fg4_launch<48, true>(s, pack, y, out, mean, rstd, h0, g, st) : fg4_launch<96, true>(s, pack, y, out, mean, rstd, h0, g, st);
+  // the fourth form's SAVE kernel is opt-in (MI_FG_CFG=v4): its stores ADD their time (918 vs 607 us at C = 48, 256^2) - every later
+  // wait on a load (weight DMA, residual, prefetch) sits behind them in the wave's in-order vmcnt - so it does not beat the chain
+  { const char* e = MI_ENV(MI_FG_CFG);
+    if (e && strstr(e, "v4"))
+      return s->C == 48 ? fg4_launch<48, true>(s, pack, y, out, mean, rstd, h0, g, st) : fg4_launch<96, true>(s, pack, y, out, mean, rstd, h0, g, st); }
   const FgSel f = fg_select(s->C, s->H);
   const FgPackLayout l = fg_pack_layout(s->C, s->hidden, f.pc);
 #define FGS_CASE(CC, TH, TW, PC, NW) \
