@@ -124,6 +124,13 @@ template <> struct Cvt<bf16> {
   static __device__ __forceinline__ bf16 from(float v) { return (bf16)v; }  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
 };
 
+// two fp32 -> one dword holding two bf16 (RNE, NaN-preserving) in ONE v_cvt_pk_bf16_f32: two scalar casts + shift/or compile
+// to a convert plus an SDWA or per pair, twice the vector instructions in every bf16 epilogue
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return to_f32(*p); }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = Cvt<T>::from(v); }
 
@@ -158,11 +165,7 @@ template <> struct Vec<bf16, 2> {
     unsigned int t = *reinterpret_cast<const unsigned int*>(p);
     o[0] = bf16_bits_to_f32(t & 0xffffu); o[1] = bf16_bits_to_f32(t >> 16);
   }
-  static __device__ __forceinline__ void st(bf16* p, const float* v) {
-    bf16 a = (bf16)v[0], b = (bf16)v[1];
-    unsigned int t = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
-    *reinterpret_cast<unsigned int*>(p) = t;
-  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) { *reinterpret_cast<unsigned int*>(p) = cvt_pk_bf16(v[0], v[1]); }
 };
 template <> struct Vec<bf16, 4> {
   static __device__ __forceinline__ void ld(const bf16* p, float* o) {
@@ -173,10 +176,7 @@ template <> struct Vec<bf16, 4> {
   static __device__ __forceinline__ void st(bf16* p, const float* v) {
     u32x2 t;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      bf16 a = (bf16)v[2 * i], b = (bf16)v[2 * i + 1];
-      t[i] = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
-    }
+    for (int i = 0; i < 2; ++i) t[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<u32x2*>(p) = t;
   }
 };
@@ -189,10 +189,7 @@ template <> struct Vec<bf16, 8> {
   static __device__ __forceinline__ void st(bf16* p, const float* v) {
     u32x4 t;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16 a = (bf16)v[2 * i], b = (bf16)v[2 * i + 1];
-      t[i] = (unsigned int)__builtin_bit_cast(u16, a) | ((unsigned int)__builtin_bit_cast(u16, b) << 16);
-    }
+    for (int i = 0; i < 4; ++i) t[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<u32x4*>(p) = t;
   }
 };

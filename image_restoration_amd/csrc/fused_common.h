@@ -39,16 +39,9 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf_s(short s) { return __uint_as_float(((unsigned int)(unsigned short)s) << 16); }
-__device__ __forceinline__ unsigned int pack_bf2(float a, float b) {
-  const bf16 x = (bf16)a, y = (bf16)b;
-  return (unsigned int)__builtin_bit_cast(u16, x) | ((unsigned int)__builtin_bit_cast(u16, y) << 16);
-}
+__device__ __forceinline__ unsigned int pack_bf2(float a, float b) { return cvt_pk_bf16(a, b); }
 // two fp32 -> one dword of two bf16 in ONE v_cvt_pk_bf16_f32 (pack_bf2's two scalar casts compile to a convert + an SDWA or)
-__device__ __forceinline__ unsigned int pk_bf2(float a, float b) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
-}
+__device__ __forceinline__ unsigned int pk_bf2(float a, float b) { return cvt_pk_bf16(a, b); }
 __device__ __forceinline__ short bf_bits(float a) { return (short)__builtin_bit_cast(u16, (bf16)a); }
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {

@@ -771,8 +771,7 @@ __device__ __forceinline__ void pww_ln_inplace(u32x4 (&raw)[KB][4], int ktot, co
           const float v0 = bf16_bits_to_f32(raw[kb][i][j] & 0xffffu), v1 = bf16_bits_to_f32(raw[kb][i][j] >> 16);
           const float o0 = mode == 1 ? (v0 - mu[2 * j]) * rs[2 * j] * g + b : v0 * rs[2 * j] * g;
           const float o1 = mode == 1 ? (v1 - mu[2 * j + 1]) * rs[2 * j + 1] * g + b : v1 * rs[2 * j + 1] * g;
-          const bf16 h0 = (bf16)o0, h1 = (bf16)o1;
-          raw[kb][i][j] = (unsigned)__builtin_bit_cast(u16, h0) | ((unsigned)__builtin_bit_cast(u16, h1) << 16);
+          raw[kb][i][j] = cvt_pk_bf16(o0, o1);
         }
       }
     }
