@@ -240,6 +240,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   gelu_parts(x, cdf, pdf);
   return x * cdf;
 }
+// Forward gate of the bf16 kernels: x sigmoid(1.6 x (1 + 0.0435 x^2)) - the tanh form of GELU with its two constants refitted
+// to the erf form (max |difference| 2.9e-4 over the reals, 1/27 of a bf16 step at 1): 5 vector instructions + exp2 + rcp
+// instead of 14 + exp + rcp, in kernels that are bound by their vector instruction count.  The fp32 (parity) instantiations and
+// every backward keep the erf form (gelu_erf / gelu_parts); MI_GELU_EXACT=1 at build time keeps it everywhere.
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x) { return gelu_erf(x); }
+#ifndef MI_GELU_EXACT
+template <> __device__ __forceinline__ float gelu_fwd<bf16>(float x) {
+  const float u = x * (-2.3083120f - 0.1004116f * x * x);            // -2 log2(e) 0.8 (x + 0.0435 x^3)
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+}
+#endif
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float cdf, pdf;
   gelu_parts(x, cdf, pdf);

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
           for (int j = 0; j < 4; ++j) { o1[j] = to_f32(Cvt<T>::from(o1[j])); o2[j] = to_f32(Cvt<T>::from(o2[j])); }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = gelu_erf(o1[j]) * o2[j];
+        for (int j = 0; j < 4; ++j) g[j] = gelu_fwd<T>(o1[j]) * o2[j];
         if (st) store4(outg + (int64_t)y * a.W, g);
         copy6(q0, q1); copy6(q1, q2);
       }
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void dws_gate_fwd2_kernel(DwArgs a, int planes
         for (int q = 0; q < 4; ++q) { o1[q] = to_f32(Cvt<T>::from(o1[q])); o2[q] = to_f32(Cvt<T>::from(o2[q])); }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g[q] = gelu_erf(o1[q]) * o2[q];
+      for (int q = 0; q < 4; ++q) g[q] = gelu_fwd<T>(o1[q]) * o2[q];
       if (st) store4(outg + (int64_t)y * a.W, g);
       copy6x2(p0, p1); copy6x2(p1, p2);
     }

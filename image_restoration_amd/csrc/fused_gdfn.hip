@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fg_fwd_kernel(FgArgs a) {
           }
           float gg[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) gg[j] = gelu_erf(o[j][0]) * o[j][1];
+          for (int j = 0; j < 8; ++j) gg[j] = gelu_fwd<bf16>(o[j][0]) * o[j][1];
           Vec<bf16, 8>::st(&G[p * K::GS + row * TW + 8 * cg], gg);
           if constexpr (SAVE) {
             if (c * PC + p < a.hidden)
@@ -1001,10 +1001,10 @@ __global__ __launch_bounds__(512, 2) void fg4_fwd_kernel(Fg4Args a) {
             if (half == 0) { y1a = d0; y1b = d1; }
             else {                                        // lane (pair li, group g): pixels 4g..4g+3 and 16+4g..16+4g+3 of row wv
               u32x4 o;
-              o[0] = pk_bf2(gelu_erf(y1a[0]) * d0[0], gelu_erf(y1a[1]) * d0[1]);
-              o[1] = pk_bf2(gelu_erf(y1a[2]) * d0[2], gelu_erf(y1a[3]) * d0[3]);
-              o[2] = pk_bf2(gelu_erf(y1b[0]) * d1[0], gelu_erf(y1b[1]) * d1[1]);
-              o[3] = pk_bf2(gelu_erf(y1b[2]) * d1[2], gelu_erf(y1b[3]) * d1[3]);
+              o[0] = pk_bf2(gelu_fwd<bf16>(y1a[0]) * d0[0], gelu_fwd<bf16>(y1a[1]) * d0[1]);
+              o[1] = pk_bf2(gelu_fwd<bf16>(y1a[2]) * d0[2], gelu_fwd<bf16>(y1a[3]) * d0[3]);
+              o[2] = pk_bf2(gelu_fwd<bf16>(y1b[0]) * d1[0], gelu_fwd<bf16>(y1b[1]) * d1[1]);
+              o[3] = pk_bf2(gelu_fwd<bf16>(y1b[2]) * d1[2], gelu_fwd<bf16>(y1b[3]) * d1[3]);
               *reinterpret_cast<u32x2*>(patch + (16 * pc + li) * K::PS + g * 8) = (u32x2){o[0], o[1]};
               *reinterpret_cast<u32x2*>(patch + (16 * pc + li) * K::PS + 32 + g * 8) = (u32x2){o[2], o[3]};
             }
