@@ -599,7 +599,8 @@ template <int C_, int HEADS_, int G_> struct Fm4Cfg : Fm3Cfg<C_, HEADS_> {
   static constexpr int H0G_BYTES = G * H0S_BYTES;
   static constexpr int VCS = 72;                           // bytes per channel row of the staging patch (64 + 8: conflict-free b64 writes)
   static constexpr int VST_BYTES = B3::NW * 16 * VCS;
-  static constexpr int A4_BYTES = ((H0G_BYTES > B3::S_BYTES ? H0G_BYTES : B3::S_BYTES) + 15) / 16 * 16;
+  static constexpr int NBUF = G < B3::NCHUNK ? 2 : 1;       // several groups: two h0 buffers, GEMM1 of group g + 1 shares a barrier interval with the wave-local phase of group g
+  static constexpr int A4_BYTES = ((NBUF * H0G_BYTES > B3::S_BYTES ? NBUF * H0G_BYTES : B3::S_BYTES) + 15) / 16 * 16;
   static constexpr int LDS4_BYTES = A4_BYTES + VST_BYTES + B3::WT_BYTES;
   static constexpr int NACC = B3::NB * B3::CB;             // Gram blocks (q block rb x the column blocks of its head), all in every wave
   static_assert(B3::NCHUNK % G == 0, "groups must tile the chunks");
@@ -743,46 +744,47 @@ __global__ __launch_bounds__(512, 2) void fm4_fwd_kernel(Fm3Args a) {
     FM4_STAMP(1);
     __syncthreads();                                      // the staged x is dead: the region becomes the h0 group
     FM4_STAMP(2);
-    if (t < 2 * G)                                        // the ones record of every chunk buffer (the staging overwrote it)
+    if (t < 2 * G * K::NBUF)                              // the ones record of every chunk buffer (the staging overwrote it)
       *reinterpret_cast<u32x4*>(H0 + (t >> 1) * K::H0S_BYTES + (K::HR * K::RW + 1) * K::REC + (t & 1) * 16) =
           (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
     s16x8 kf[NB];                                         // this wave's k fragments (tile row wv: 16 channels x 32 pixels each)
+    // GEMM1 of group grp: h0[chunk][pixel][16 ch] = W' LN(x) + b' (0 outside the image), into h0 buffer grp % NBUF
+    auto gemm1 = [&](const int grp) {
+      int lane_c = lane_outer;
+      asm volatile("" : "+v"(lane_c));
+      const int lane = lane_c;
+      const unsigned char* const wf = W1 + lane * 16;
+      s16x8 bw[K::NKS], bwn[K::NKS];
+#pragma unroll
+      for (int ks = 0; ks < K::NKS; ++ks) bw[ks] = *reinterpret_cast<const s16x8*>(wf + ((grp * G) * K::NKS + ks) * K::FRAG);
+#pragma unroll
+      for (int cg = 0; cg < G; ++cg) {
+        const int ci = grp * G + cg;
+        if (cg + 1 < G) {                               // the next chunk's weights are requested before this chunk's stores
+#pragma unroll
+          for (int ks = 0; ks < K::NKS; ++ks) bwn[ks] = *reinterpret_cast<const s16x8*>(wf + ((ci + 1) * K::NKS + ks) * K::FRAG);
+        }
+        unsigned char* const h = H0 + (grp % K::NBUF) * K::H0G_BYTES + cg * K::H0S_BYTES;
+#pragma unroll
+        for (int i = 0; i < K::MTW; ++i) {              // (m-tiles past the last one multiply the last again and land in the dummy record)
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < K::KS32; ++ks) d = mfma32(bw[ks], xa[i][ks], d);
+          d = mfma32(bw[K::KS32], xt[i], d);
+          *reinterpret_cast<u32x2*>(h + recoff[i]) = (u32x2){pk_bf2(d[0], d[1]), pk_bf2(d[2], d[3])};
+        }
+        if (cg + 1 < G) {
+#pragma unroll
+          for (int ks = 0; ks < K::NKS; ++ks) bw[ks] = bwn[ks];
+        }
+        __builtin_amdgcn_sched_barrier(0);              // one chunk's accumulators at a time
+      }
+    };
+
+    gemm1(0);
 #pragma unroll
     for (int grp = 0; grp < K::NG; ++grp) {
-      if (grp > 0) __syncthreads();                       // the previous group's conv is done with H0
-      // ------------------------------------------------------------ GEMM1 of the group: h0[chunk][pixel][16 ch] = W' LN(x) + b' (0 outside the image)
-      {
-        int lane_c = lane_outer;
-        asm volatile("" : "+v"(lane_c));
-        const int lane = lane_c;
-        const unsigned char* const wf = W1 + lane * 16;
-        s16x8 bw[K::NKS], bwn[K::NKS];
-#pragma unroll
-        for (int ks = 0; ks < K::NKS; ++ks) bw[ks] = *reinterpret_cast<const s16x8*>(wf + ((grp * G) * K::NKS + ks) * K::FRAG);
-#pragma unroll
-        for (int cg = 0; cg < G; ++cg) {
-          const int ci = grp * G + cg;
-          if (cg + 1 < G) {                               // the next chunk's weights are requested before this chunk's stores
-#pragma unroll
-            for (int ks = 0; ks < K::NKS; ++ks) bwn[ks] = *reinterpret_cast<const s16x8*>(wf + ((ci + 1) * K::NKS + ks) * K::FRAG);
-          }
-          unsigned char* const h = H0 + cg * K::H0S_BYTES;
-#pragma unroll
-          for (int i = 0; i < K::MTW; ++i) {              // (m-tiles past the last one multiply the last again and land in the dummy record)
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < K::KS32; ++ks) d = mfma32(bw[ks], xa[i][ks], d);
-            d = mfma32(bw[K::KS32], xt[i], d);
-            *reinterpret_cast<u32x2*>(h + recoff[i]) = (u32x2){pk_bf2(d[0], d[1]), pk_bf2(d[2], d[3])};
-          }
-          if (cg + 1 < G) {
-#pragma unroll
-            for (int ks = 0; ks < K::NKS; ++ks) bw[ks] = bwn[ks];
-          }
-          __builtin_amdgcn_sched_barrier(0);              // one chunk's accumulators at a time
-        }
-      }
       FM4_STAMP(3);
       if (grp == K::NG - 1 && tile + 1 < t1) {            // the next tile's x leaves HBM behind the last group's wave-local work
         const int nt_ = tile + 1;
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(512, 2) void fm4_fwd_kernel(Fm3Args a) {
       }
       __syncthreads();
       FM4_STAMP(4);
+      if (K::NBUF == 2 && grp + 1 < K::NG) gemm1(grp + 1);   // into the other h0 buffer, inside this barrier interval
       // ------------------------------------------------------------ wave-local: conv, Gram, stores of tile row wv
       {
         int lane_c = lane_outer;
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void fm4_fwd_kernel(Fm3Args a) {
         // byte addresses of the A-operand reads of chunk 0: (k-step, pixel half); chunk cg adds cg * H0S_BYTES as an immediate.
         // k-step s contracts taps 2s (lanes g < 2) and 2s + 1 (g >= 2); the tenth "tap" is the depthwise bias against the ones record
         unsigned aA[5][2];
-        const unsigned h0base = (unsigned)(uintptr_t)H0;
+        const unsigned h0base = (unsigned)(uintptr_t)(H0 + (grp % K::NBUF) * K::H0G_BYTES);
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
           const int tp = 2 * s + (g >> 1);
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void fm4_fwd_kernel(Fm3Args a) {
           }
           if constexpr (SAVE) {                           // qkv0 of row wv: records -> channel rows (transposing reads), 64-byte segments
             const int qq = li >> 2, pp = li & 3;
-            const unsigned char* hr = H0 + cg * K::H0S_BYTES;
+            const unsigned char* hr = H0 + (grp % K::NBUF) * K::H0G_BYTES + cg * K::H0S_BYTES;
             const int rs = (wv + 1) * K::RW + 1 + 8 * g + qq;
             // per 16-lane group g: pixels 8g..8g+7; lane 4q+p supplies record (pixel) q of a 4-pixel block, channels 4p..4p+3
             s16x4 u0 = tr_b16(hr + fm4_rec(rs, pp));
@@ -1119,6 +1122,8 @@ extern "C" int mi_mdta_fused_fwd(const mi_mdta_shape* s, const mi_mdta_params* p
     else if (k == FM_96_2) MI_TRY((fm_launch<96, 2, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
     else MI_TRY((fm_launch<96, 1, 8, 8>(s, l, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, st)));
   } else {                                                // fourth form: the conv on the matrix cores, grouped phases, wave-local Gram
+    // one group of all 9 chunks: 308 us at 256^2, bs 32; three double-buffered groups of 3 (GEMM1 of group g + 1 inside the
+    // wave-local interval of group g) were measured at 418 us - two more barriers per tile cost more than the overlap buys
     MI_TRY((fm4_launch<48, 1, 9, false>(s, pack, x, w.v, w.part, mean, rstd, ln_with_bias, S, nullptr, nullptr, st)));
     part_mult = 8;
   }
