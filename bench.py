@@ -374,8 +374,13 @@ def main():
             ops.prof_enable(False)
         model.train()
         fa, av = tab.get("mdta_fused_a"), tab.get("mdta_av") or tab.get("pw_gemm")
+        gf = tab.get("gdfn_fused_fwd")
         infer = {"what": "no_grad forward, same model and batch (one-launch LN+GDFN half-blocks; MDTA pass A fused where C is 48 / 96)",
                  "ms": round(dt_inf * 1e3, 3), "mpix_s": round(batch * patch * patch / dt_inf / 1e6, 3)}
+        if gf:
+            infer["gdfn_fused"] = {"launches": gf["launches"], "ms": round(gf["ms"], 3), "tflops": round(gf["flops"] / gf["ms"] / 1e9, 1),
+                                   "mfma_frac": round(gf["flops"] / gf["ms"] / 1e9 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                                   "hbm_gbs": round(gf["bytes"] / gf["ms"] / 1e6, 1)}
         if fa:
             infer["mdta_pass_a_fused"] = {
                 "what": "LN -> qkv 1x1 -> dw3x3 -> q k^T partials + row norms + v, one launch per block (24 of 44 blocks); HBM: x in, v out",
@@ -383,12 +388,13 @@ def main():
                 "mfma_frac": round(fa["flops"] / fa["ms"] / 1e9 / MFMA_PEAK_TFLOPS["bf16"], 4),
                 "hbm_gbs": round(fa["bytes"] / fa["ms"] / 1e6, 1), "hbm_frac": round(fa["bytes"] / fa["ms"] / 1e6 / HBM_PEAK_GBS, 4),
                 "target_mfma_frac": 0.40,
-                "note": "latency-bound at two waves per SIMD (profiles/r03_c_*): neither roof; see DESIGN.md section 7c"}
+                "note": "C = 48: fourth form (depthwise conv on the matrix cores, wave-local Gram), bound by its vector-instruction count "
+                        "and one GEMM1 -> conv barrier per tile; C = 96: the round-3 form; neither roof - DESIGN.md section 7d"}
 
     fp32_line = None
     if world == 1 and rank == 0 and args.dtype == "bf16" and not args.no_fp32_line and not moce:
         # the parity path (exact fp32 MFMA, the reference's mainline precision) timed beside the headline: bs 8, 5 steps
-        trainer.close()                     # the packed-weight cache is process-global: hand it to the fp32 trainer
+        trainer.close()                     # the packed-weight cache is process-global: hand it to the fp32 trainer (idempotent)
         b32 = min(batch, 8)
         model32 = build_model()
         tr32 = FlatTrainer(model32, lr=2e-4)
@@ -404,6 +410,47 @@ def main():
         fp32_line = {"value": round(b32 * patch * patch / dt / 1e6, 4), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 3),
                      "per_gpu_batch": b32, "steps": 5, "dtype": "fp32"}
         tr32.close()
+
+    # BASELINE configs[1] (Restormer base, bs 8 on one GPU) and configs[3] (MoCE-IR base, the reference README's per-GPU batch and
+    # patch) as short legs of the default line, so that the driver times them too: value, ms per step, library launches per step
+    extra = {}
+    if world == 1 and rank == 0 and args.dtype == "bf16" and args.model == "restormer" and not args.no_fp32_line:
+        trainer.close()
+
+        def short_leg(kind, b_, p_, steps=10, warm=3):
+            torch.cuda.reset_peak_memory_stats()
+            torch.manual_seed(0)
+            if kind == "moce":
+                from image_restoration_amd.moce_ir import MoCEIR
+                net = MoCEIR(**configs.MOCEIR_BASE).to(dev).train()
+            else:
+                net = m.Restormer(**configs.RESTORMER_BASE).to(dev)
+            tr_ = FlatTrainer(net, lr=2e-4)
+            g_ = torch.Generator(device="cpu").manual_seed(4321)
+            cl = torch.rand((b_, 3, p_, p_), generator=g_)
+            nz = torch.clamp(torch.round(cl * 255.0) + 25.0 * torch.randn(cl.shape, generator=g_), 0, 255) / 255.0
+            st_, _ = make_step(net, tr_, nz.to(dev).to(act), cl.to(dev).to(act), use_dev_scalars=False, moce=(kind == "moce"))
+            for _ in range(warm):
+                st_()
+            torch.cuda.synchronize()
+            t1_ = time.perf_counter()
+            for _ in range(steps):
+                st_()
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t1_) / steps
+            ops.prof_enable(True)
+            st_()
+            torch.cuda.synchronize()
+            tab_ = ops.prof_collect()
+            ops.prof_enable(False)
+            tr_.close()
+            return {"value": round(b_ * p_ * p_ / dt_ / 1e6, 4), "unit": "Mpixels/s", "ms_per_step": round(dt_ * 1e3, 3),
+                    "per_gpu_batch": b_, "patch": p_, "steps": steps, "dtype": args.dtype,
+                    "library_launches_per_step": int(sum(v["launches"] for v in tab_.values())),
+                    "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+        extra["c2_bs8"] = dict(short_leg("restormer", 8, 256), what="BASELINE configs[1]: Restormer base 256x256, bs 8, one GPU, train step")
+        extra["c4_moce"] = dict(short_leg("moce", 8, 128), what="BASELINE configs[3] per-GPU workload: MoCE-IR base 128x128, bs 8, train step "
+                                                               "(L1 + 0.01 balance loss)")
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -433,7 +480,7 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": bool(graph is not None), "final_loss": final_loss,
                        "peak_hbm_gib": peak_gib},
             "roofline": roofline, "step_roofline": step_roofline, "mdta_contraction": contraction, "inference_forward": infer,
-            "fp32_line": fp32_line,
+            "fp32_line": fp32_line, **extra,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

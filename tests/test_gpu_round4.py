@@ -19,7 +19,7 @@ def M():
 
 
 def rel(a, b):
-    a, b = a.double(), b.double()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
@@ -179,3 +179,81 @@ def test_deferred_flush_refuses_a_capturing_stream():
         assert ops.deferred_pending() == 0
     finally:
         tr.close()
+
+
+# ----------------------------------------------------------------------------------------------- fused half-blocks, real planes
+def _seeded(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("c,heads,hw,batch", [(48, 1, 256, 8), (96, 2, 128, 32), (96, 1, 256, 8)])
+def test_fused_mdta_at_the_training_plane_vs_oracle_and_chain(c, heads, hw, batch):
+    """Round-3 verdict, weak 1(c): the fused pass A (C = 48: the fourth form - depthwise conv on the matrix cores, wave-local Gram -
+    C = 96: the round-3 form) in the regime it ships in: 8 x C x 256^2 / 128^2, one persistent workgroup per CU walking many
+    tiles.  Against the fp64 oracle on the first two images (host time) and against the unfused chain on all of them."""
+    m = M()
+    from image_restoration_amd import ops
+    from oracle import restormer_ref as R
+    sd = R.make_block_state(c, heads, 2.66, False, "WithBias", seed=400 + c + heads)
+    x = _seeded((batch, c, hw, hw), 4100 + c).to(DEV).to(torch.bfloat16)
+    ln = (sd["norm1.body.weight"].to(DEV), sd["norm1.body.bias"].to(DEV))
+    keys = ["attn.temperature", "attn.qkv.weight", "attn.qkv.bias", "attn.qkv_dwconv.weight", "attn.qkv_dwconv.bias",
+            "attn.project_out.weight", "attn.project_out.bias"]
+    att = tuple(sd[k].to(DEV).float().contiguous() if k in sd else None for k in keys)
+    assert ops.mdta_fused_ok(x, heads, 3) and ops.mdta_fused_pays(x, heads, 3)
+    pack = ops.mdta_fused_pack(x, heads, ln[0], ln[1], att)
+    y, mean, rstd = ops.mdta_fused_fwd(x, pack, att, heads, True, x, want_stats=True)
+    xn, mean_r, rstd_r = ops.ln_fwd(x, ln[0], ln[1], True, want_stats=True)
+    chain, _ = ops.mdta_fwd(xn, x, att, heads, False)
+    assert rel(mean, mean_r) < 1e-5 and rel(rstd, rstd_r) < 1e-4
+    x2 = x[:2].float().cpu().double()
+    d = {k: v.double() for k, v in sd.items()}
+    xn2 = R.layernorm_nchw(x2, d["norm1.body.weight"], d.get("norm1.body.bias"), "WithBias")
+    ref = x2 + R.mdta(xn2, d["attn.temperature"], d["attn.qkv.weight"], d["attn.qkv_dwconv.weight"], d["attn.project_out.weight"], heads,
+                      d.get("attn.qkv.bias"), d.get("attn.qkv_dwconv.bias"), d.get("attn.project_out.bias"))
+    e_or, e_ch = rel(y[:2], ref), rel(chain[:2], ref)
+    assert e_or < 2e-2, (e_or, e_ch)
+    assert e_or < 1.5 * e_ch + 4e-3, (e_or, e_ch)
+    assert rel(y, chain.double()) < 2e-2                      # every image, against the chain
+
+
+@pytest.mark.parametrize("c,hidden,hw,batch", [(48, 127, 256, 8), (96, 255, 128, 8)])
+def test_fused_gdfn_at_the_training_plane_vs_oracle_and_chain(c, hidden, hw, batch):
+    """The one-launch LN + GDFN half-block (C = 48: the fourth form) in its persistent regime, inference and SAVE forms: output against
+    the fp64 oracle (two images) and the chain (all), and the saved blob against what the chain saves."""
+    m = M()
+    from image_restoration_amd import ops
+    from oracle import restormer_ref as R
+    sd = R.make_block_state(c, 1, 2.66, False, "WithBias", seed=470 + c)
+    y = _seeded((batch, c, hw, hw), 4700 + c).to(DEV).to(torch.bfloat16)
+    ln_w, ln_b = sd["norm2.body.weight"].to(DEV), sd["norm2.body.bias"].to(DEV)
+    keys = ["ffn.project_in.weight", "ffn.project_in.bias", "ffn.dwconv.weight", "ffn.dwconv.bias", "ffn.project_out.weight",
+            "ffn.project_out.bias"]
+    params = tuple(sd[k].to(DEV).float().contiguous() if k in sd else None for k in keys)
+    assert params[0].shape[0] == 2 * hidden
+    pack = ops.gdfn_fused_pack(y, ln_w, ln_b, params)
+    out, mean, rstd = ops.gdfn_fused_fwd(y, pack, hidden, True, want_stats=True)
+    chain = ops.gdfn_fwd(y, y, params, True, ln=(ln_w, ln_b, True))
+    chain_out = chain[0] if isinstance(chain, (tuple, list)) else chain
+    y2 = y[:2].float().cpu().double()
+    d = {k: v.double() for k, v in sd.items()}
+    yn2 = R.layernorm_nchw(y2, d["norm2.body.weight"], d.get("norm2.body.bias"), "WithBias")
+    ref = y2 + R.gdfn(yn2, d["ffn.project_in.weight"], d["ffn.dwconv.weight"], d["ffn.project_out.weight"], d.get("ffn.project_in.bias"),
+                      d.get("ffn.dwconv.bias"), d.get("ffn.project_out.bias"))
+    e_or, e_ch = rel(out[:2], ref), rel(chain_out[:2], ref)
+    assert e_or < 2e-2, (e_or, e_ch)
+    assert e_or < 1.5 * e_ch + 4e-3, (e_or, e_ch)
+    assert rel(out, chain_out.double()) < 2e-2
+    out_t, saved, mean_t, rstd_t = ops.gdfn_fused_fwd_train(y, pack, hidden, True)
+    assert rel(out_t, out.double()) < 1e-2 and rel(mean_t, mean) < 1e-5 and rel(rstd_t, rstd) < 1e-4
+
+
+def test_forward_gelu_of_the_bf16_kernels_stays_within_its_stated_bound():
+    """common.h gelu_fwd<bf16>: x sigmoid(1.6 x (1 + 0.0435 x^2)), |difference to the erf form| <= 3e-4 (stated in the header);
+    checked here on the formula itself in fp64 over a dense grid (the kernels' outputs are covered by the oracle tests above)."""
+    import math
+    x = torch.linspace(-12, 12, 480001, dtype=torch.float64)
+    exact = x * 0.5 * (1 + torch.erf(x / math.sqrt(2)))
+    u = x * (-2.3083120 - 0.1004116 * x * x)
+    fast = x / (1 + torch.exp2(u))
+    assert float((fast - exact).abs().max()) < 3.0e-4
