@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def parse():
