@@ -27,7 +27,8 @@ class PwDesc(C.Structure):
                 ("m", C.c_int), ("n", c_i64), ("batch", C.c_int), ("groups", C.c_int), ("dtype", C.c_int),
                 ("ln_w", fp), ("ln_b", fp), ("ln_mean", fp), ("ln_rstd", fp), ("ln_mode", C.c_int),
                 ("f8", C.c_int), ("f8_sx", C.c_float), ("f8_sw", C.c_float),
-                ("y_split", C.c_int), ("y2", vp), ("y2_bs", c_i64), ("y2_gs", c_i64)]
+                ("y_split", C.c_int), ("y2", vp), ("y2_bs", c_i64), ("y2_gs", c_i64),
+                ("w_b16", vp), ("w_b16_sm", c_i64)]
 
 
 class GramDesc(C.Structure):

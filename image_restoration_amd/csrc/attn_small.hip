@@ -79,7 +79,8 @@ template <int CT>
 __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ graw, const float* __restrict__ ss,
                                                         const float* __restrict__ temperature, const float* __restrict__ wo,
                                                         float* __restrict__ P, float* __restrict__ A, float* __restrict__ nrm,
-                                                        float* __restrict__ M, int C, int heads, int ld) {
+                                                        float* __restrict__ M, bf16* __restrict__ Mb, bf16* __restrict__ Mtb, int C,
+                                                        int heads, int ld) {
   extern __shared__ float sm[];
   const int c = C / heads;
   float* As = sm;               // [c][ld]
@@ -122,7 +123,12 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < CT; ++q) {
       const int j = tj + 16 * q;
-      if (j < c) M[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = acc[q];
+      if (j < c) {
+        M[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = acc[q];
+        // bf16 copies for the per-image-weight GEMMs (mi_pw_desc.w_b16): M_b for out = M_b v, its transpose for dv = M_b^T dy
+        if (Mb) Mb[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = (bf16)acc[q];
+        if (Mtb) Mtb[(int64_t)b * C * C + (int64_t)(h * c + j) * C + r] = (bf16)acc[q];
+      }
     }
   }
 }
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
                                                               const float* __restrict__ A, const float* __restrict__ P,
                                                               const float* __restrict__ nrm,
                                                               const float* __restrict__ temperature,
-                                                              float* __restrict__ dtemp_part, float* __restrict__ wd,
+                                                              float* __restrict__ dtemp_part, float* __restrict__ wd, bf16* __restrict__ wdb,
                                                               int C, int heads) {
   __shared__ float colp[16 * ATTN_MAX_C];
   __shared__ float rqs[ATTN_MAX_C], rks[ATTN_MAX_C], red[4];
@@ -340,8 +346,16 @@ __global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __res
       wk[j * 2 * c + c + i] = g1;        // dk_j += g1 * q_i
       // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
       const float nki = nz[c + i];
-      wq[i * 2 * c + c + j] = (i == j) ? ((nq > NORM_EPS) ? -rqs[i] / (nq * nq) : 0.f) : 0.f;
-      wk[i * 2 * c + j] = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
+      const float dq_ = (i == j) ? ((nq > NORM_EPS) ? -rqs[i] / (nq * nq) : 0.f) : 0.f;
+      const float dk_ = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
+      wq[i * 2 * c + c + j] = dq_;
+      wk[i * 2 * c + j] = dk_;
+      if (wdb) {                         // the same matrix in bf16 for the q / k gradient GEMM (mi_pw_desc.w_b16)
+        bf16* bq = wdb + (int64_t)z * 2 * c * 2 * c;
+        bf16* bk = bq + (int64_t)c * 2 * c;
+        bq[i * 2 * c + j] = (bf16)g1; bk[j * 2 * c + c + i] = (bf16)g1;
+        bq[i * 2 * c + c + j] = (bf16)dq_; bk[i * 2 * c + j] = (bf16)dk_;
+      }
     }
   }
 }
@@ -419,7 +433,7 @@ size_t attn_bwd_scratch_floats(int B, int C, int heads) {
 }
 
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
-                     float* nrm, float* M, int B, int C, int heads, hipStream_t st) {
+                     float* nrm, float* M, int B, int C, int heads, hipStream_t st, void* Mb, void* Mtb) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   const int ld = attn_ld(c);
@@ -429,7 +443,8 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
   ATTN_CT_SWITCH(attn_ct(c), {
     if (lds > 64 * 1024)
       MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fold_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attn_fold_kernel<CT>), grid, dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, C, heads, ld);
+    hipLaunchKernelGGL((attn_fold_kernel<CT>), grid, dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, (bf16*)Mb, (bf16*)Mtb, C,
+                       heads, ld);
   });
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -438,7 +453,7 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
 // scratch: attn_bwd_scratch_floats() floats for the per-chunk dA partials
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
                           const float* wo, float* dwo_part, float* dtemp_part, float* wd, float* scratch,
-                          int B, int C, int heads, hipStream_t st) {
+                          int B, int C, int heads, hipStream_t st, void* wdb) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
   MI_CHECK_ARG(scratch, "mdta: null attention scratch");
@@ -452,7 +467,7 @@ int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const
     hipLaunchKernelGGL((attn_bwd_partial_kernel<CT>), dim3(B * heads, rch), dim3(256), lds, st, dM, A, wo, scratch, dwo_part, C,
                        heads, ld);
     hipLaunchKernelGGL((attn_bwd_finish_kernel<CT>), dim3(B * heads), dim3(256), 0, st, (const float*)scratch, rch, A, P, nrm,
-                       temperature, dtemp_part, wd, C, heads);
+                       temperature, dtemp_part, wd, (bf16*)wdb, C, heads);
   });
   MI_LAUNCH_CHECK();
   return MI_OK;

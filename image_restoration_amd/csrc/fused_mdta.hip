@@ -963,7 +963,7 @@ static int fm_splits(const mi_mdta_shape* s, int TH) {
   return S;
 }
 
-struct FmWs { void* v; float* part; float* graw; float* ss; float* P; float* A; float* nrm; float* M; void* pw_ws; size_t bytes; };
+struct FmWs { void* v; float* part; float* graw; float* ss; float* P; float* A; float* nrm; float* M; void* Mb; void* pw_ws; size_t bytes; };
 static FmWs fm_ws_layout(const mi_mdta_shape* s, void* base) {
   const size_t N = (size_t)s->H * s->W, C = s->C, B = s->B, c = C / s->heads, Z = B * s->heads;
   Carver cv(base);
@@ -976,6 +976,7 @@ static FmWs fm_ws_layout(const mi_mdta_shape* s, void* base) {
   w.A = cv.take<float>(Z * c * c * sizeof(float));
   w.nrm = cv.take<float>(Z * 2 * c * sizeof(float));
   w.M = cv.take<float>(B * C * C * sizeof(float));
+  w.Mb = cv.take(B * C * C * 2);                          // bf16 M_b for the per-image-weight GEMM (mi_pw_desc.w_b16)
   {
     mi_pw_desc d;
     memset(&d, 0, sizeof(d));
@@ -1134,12 +1135,13 @@ extern "C" int mi_mdta_fused_fwd(const mi_mdta_shape* s, const mi_mdta_params* p
                        S * part_mult, s->C, s->heads);
     MI_LAUNCH_CHECK();
   }
-  MI_TRY(launch_attn_fold(w.graw, w.ss, p->temperature, p->proj_w, w.P, w.A, w.nrm, w.M, s->B, s->C, s->heads, st));
+  MI_TRY(launch_attn_fold(w.graw, w.ss, p->temperature, p->proj_w, w.P, w.A, w.nrm, w.M, s->B, s->C, s->heads, st, w.Mb, nullptr));
   const int64_t N = (int64_t)s->H * s->W;
   mi_pw_desc d;
   memset(&d, 0, sizeof(d));
   d.x1 = w.v; d.x1_bs = (int64_t)s->C * N; d.k1 = s->C;
   d.w = w.M; d.w_sm = s->C; d.w_sk = 1; d.w_bs = (int64_t)s->C * s->C;
+  d.w_b16 = w.Mb; d.w_b16_sm = s->C;
   d.bias = p->proj_b;
   d.r = residual; d.r_bs = (int64_t)s->C * N;
   d.y = out; d.y_bs = (int64_t)s->C * N;

@@ -15,10 +15,10 @@ struct PwK {
   void* y2; int64_t y2_bs, y2_gs; int y_split;   // rows >= y_split go to y2 (wave-owned forms, no residual); 0 = one output
 };
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
-                     float* nrm, float* M, int B, int C, int heads, hipStream_t st);
+                     float* nrm, float* M, int B, int C, int heads, hipStream_t st, void* Mb = nullptr, void* Mtb = nullptr);
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
                           const float* wo, float* dwo_part, float* dtemp_part, float* wd, float* scratch,
-                          int B, int C, int heads, hipStream_t st);
+                          int B, int C, int heads, hipStream_t st, void* wdb = nullptr);
 size_t attn_bwd_scratch_floats(int B, int C, int heads);
 size_t chan_sum_workspace(int C, int64_t N);
 int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtype, int accumulate, void* ws, hipStream_t st);

@@ -75,9 +75,9 @@ static int co_join(hipStream_t side, hipStream_t st) {
 // groups of c = C/heads rows (Restormer.py:117-119 'b (head c) h w').
 struct QkvView { const void* q; int64_t q_bs; const void* k; int64_t k_bs; const void* v; int64_t v_bs; };
 struct AttnDims { int B, C, heads, dtype; int64_t N; };
-struct AttnSaved { float* A; float* P; float* nrm; float* M; };
+struct AttnSaved { float* A; float* P; float* nrm; float* M; void* Mb; void* Mtb; };   // Mb / Mtb: bf16 M_b and M_b^T (mi_pw_desc.w_b16)
 struct AttnScratch {
-  float* graw; float* ss; float* dM; float* dwo_part; float* dtemp_part; float* wd; float* attn_scr;
+  float* graw; float* ss; float* dM; float* dwo_part; float* dtemp_part; float* wd; float* attn_scr; void* wdb;
   void* gram_ws; void* pw_ws; void* cs_ws;
 };
 
@@ -87,6 +87,8 @@ static void attn_saved_carve(Carver& cv, const AttnDims& d, AttnSaved* r) {
   r->P = cv.take<float>(fbytes(Z * c * c));
   r->nrm = cv.take<float>(fbytes(Z * 2 * c));
   r->M = cv.take<float>(fbytes(B * C * C));
+  r->Mb = cv.take(B * C * C * 2);
+  r->Mtb = cv.take(B * C * C * 2);
 }
 
 static mi_gram_desc attn_qk_gram(const AttnDims& d, const QkvView& v, float* graw, float* ss) {
@@ -120,20 +122,23 @@ static mi_gram_desc wgrad_gram(const void* dy, int m, const void* x, int k, int 
 }
 // the grouped per-image GEMM(s) of the q/k gradients over the stacked operand [k; q] (two K-panels of c rows each); weights
 // [Z][2c][2c] (attn_bwd_finish_kernel): rows 0..c-1 give dq, rows c..2c-1 give dk.  rows = 2c with a second output: both in one pass.
-static mi_pw_desc attn_dqk_desc(const AttnDims& d, const QkvView& v, const float* w, int row0, int rows, void* y, int64_t y_bs) {
+static mi_pw_desc attn_dqk_desc(const AttnDims& d, const QkvView& v, const float* w, int row0, int rows, void* y, int64_t y_bs,
+                                const void* wb = nullptr) {
   const int c = d.C / d.heads;
   mi_pw_desc dd;
   memset(&dd, 0, sizeof(dd));
   dd.x1 = v.k; dd.x1_bs = v.k_bs; dd.x1_gs = (int64_t)c * d.N; dd.k1 = c;
   dd.x2 = v.q; dd.x2_bs = v.q_bs; dd.x2_gs = (int64_t)c * d.N; dd.k2 = c;
   dd.w = w + (int64_t)row0 * 2 * c; dd.w_bs = (int64_t)d.heads * 2 * c * 2 * c; dd.w_gs = (int64_t)2 * c * 2 * c; dd.w_sm = 2 * c; dd.w_sk = 1;
+  if (wb) { dd.w_b16 = (const char*)wb + (int64_t)row0 * 2 * c * 2; dd.w_b16_sm = 2 * c; }
   dd.y = y; dd.y_bs = y_bs; dd.y_gs = (int64_t)c * d.N;
   dd.m = rows; dd.n = d.N; dd.batch = d.B; dd.groups = d.heads; dd.dtype = d.dtype;
   return dd;
 }
-static mi_pw_desc attn_dqk_merged(const AttnDims& d, const QkvView& v, const float* w, void* dq, int64_t dq_bs, void* dk, int64_t dk_bs) {
+static mi_pw_desc attn_dqk_merged(const AttnDims& d, const QkvView& v, const float* w, void* dq, int64_t dq_bs, void* dk, int64_t dk_bs,
+                                  const void* wb = nullptr) {
   const int c = d.C / d.heads;
-  mi_pw_desc dd = attn_dqk_desc(d, v, w, 0, 2 * c, dq, dq_bs);
+  mi_pw_desc dd = attn_dqk_desc(d, v, w, 0, 2 * c, dq, dq_bs, wb);
   dd.y_split = c; dd.y2 = dk; dd.y2_bs = dk_bs; dd.y2_gs = (int64_t)c * d.N;
   return dd;
 }
@@ -146,6 +151,7 @@ static void attn_scratch_carve(Carver& cv, const AttnDims& d, AttnScratch* w) {
   w->dwo_part = cv.take<float>(fbytes(B * C * C));
   w->dtemp_part = cv.take<float>(fbytes(Z));
   w->wd = cv.take<float>(fbytes(Z * 2 * c * 2 * c));     // [Z][2c][2c]: rows of dq, then rows of dk, over the stacked [k; q]
+  w->wdb = cv.take(Z * 2 * c * 2 * c * 2);               // the same in bf16
   w->attn_scr = cv.take<float>(fbytes(attn_bwd_scratch_floats((int)B, (int)C, d.heads)));
   QkvView fake{(void*)256, 0, (void*)256, 0, (void*)256, 0};
   mi_gram_desc g1 = attn_qk_gram(d, fake, (float*)256, (float*)256);
@@ -175,10 +181,11 @@ static int attn_core_fwd(const AttnDims& d, const QkvView& v, const float* tempe
   hipStream_t st = (hipStream_t)stream;
   mi_gram_desc g = attn_qk_gram(d, v, w.graw, w.ss);
   MI_TRY(mi_gram(&g, w.gram_ws, stream));
-  MI_TRY(launch_attn_fold(w.graw, w.ss, temperature, proj_w, sv.P, sv.A, sv.nrm, sv.M, d.B, d.C, d.heads, st));
+  MI_TRY(launch_attn_fold(w.graw, w.ss, temperature, proj_w, sv.P, sv.A, sv.nrm, sv.M, d.B, d.C, d.heads, st, sv.Mb, sv.Mtb));
   mi_pw_desc d2 = conv1x1(v.v, d.C, sv.M, false, d.C, proj_b, residual, out, d.C, d.B, d.N, d.dtype);
   d2.x1_bs = v.v_bs;
   d2.w_bs = (int64_t)d.C * d.C;
+  d2.w_b16 = sv.Mb; d2.w_b16_sm = d.C;
   if (f8) { d2.f8 = 1; d2.f8_sx = f8->x2; d2.f8_sw = f8->w2; }
   return mi_pw_gemm(&d2, w.pw_ws, stream);
 }
@@ -201,25 +208,26 @@ static int attn_core_bwd(const AttnDims& d, const QkvView& v, const void* dout, 
     if (a1 && a2) { dwo_part = a1; dtemp_part = a2; }
   }
   MI_TRY(launch_attn_bwd_small(w.dM, sv.A, sv.P, sv.nrm, temperature, proj_w, dwo_part, dtemp_part, w.wd,
-                               w.attn_scr, B, C, hd, st));
+                               w.attn_scr, B, C, hd, st, w.wdb));
   MI_TRY(launch_reduce_rows(dwo_part, g_proj_w, B, (int64_t)C * C, (int64_t)C * C, acc, 1.0f, st));
   MI_TRY(launch_reduce_rows(dtemp_part, g_temperature, B, hd, hd, acc, 1.0f, st));
   // dq = G1 k + D1 q ; dk = G1^T q + D2 k   (grouped over heads, per-image weights)
   // both in one pass over q and k where the GEMM form can write two outputs (bf16 wave-owned forms), else one GEMM each
   const int c = C / hd;
-  mi_pw_desc dd = attn_dqk_merged(d, v, w.wd, dq, dq_bs, dk, dk_bs);
+  mi_pw_desc dd = attn_dqk_merged(d, v, w.wd, dq, dq_bs, dk, dk_bs, w.wdb);
   if (mi_pw_gemm_split_ok(&dd) && !MI_ENV(MI_ATTN_DQK_SPLIT)) {
     MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
   } else {
-    dd = attn_dqk_desc(d, v, w.wd, 0, c, dq, dq_bs);
+    dd = attn_dqk_desc(d, v, w.wd, 0, c, dq, dq_bs, w.wdb);
     MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
-    dd = attn_dqk_desc(d, v, w.wd, c, c, dk, dk_bs);
+    dd = attn_dqk_desc(d, v, w.wd, c, c, dk, dk_bs, w.wdb);
     MI_TRY(mi_pw_gemm(&dd, w.pw_ws, stream));
   }
   // dv = M_b^T dY
   mi_pw_desc dvd = conv1x1(dout, C, sv.M, true, C, nullptr, nullptr, dv, C, B, d.N, d.dtype);
   dvd.w_bs = (int64_t)C * C;
   dvd.y_bs = dv_bs;
+  dvd.w_b16 = sv.Mtb; dvd.w_b16_sm = C;                  // M_b^T, written row-major by attn_fold
   return mi_pw_gemm(&dvd, w.pw_ws, stream);
 }
 

@@ -110,6 +110,7 @@ struct PwG {
   const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; int ln_mode;   // 0 none, 1 WithBias, 2 BiasFree
   int xcd_map;              // stream form: XCD-aware workgroup order (see the kernel)
   int w_direct;             // wave forms: stage the weights straight from the fp32 matrix k.w (per-image weights: no pack launch)
+  const bf16* wb16; int64_t wb16_sm;   // ... or from their bf16 copy (mi_pw_desc.w_b16): 16-byte copies, what the packed path's staging costs
   float f8_sx, f8_sw;       // fp8 operand forms: X / f8_sx and W / f8_sw are rounded to e4m3, the accumulator is scaled by their product
 };
 
@@ -638,6 +639,21 @@ __device__ __forceinline__ void pww_stage_weights_f32(bf16* Wl, const float* __r
     Wl[(img * tm + mm) * WS_ROW + kk] = (bf16)v;
   }
 }
+// The same from the bf16 copy a producer wrote beside its fp32 matrix (mi_pw_desc.w_b16: row-major, unit k stride, everything a
+// multiple of 8): whole 16-byte vectors, i.e. exactly the loads and LDS stores pww_stage_weights spends on a packed image.
+__device__ __forceinline__ void pww_stage_weights_b16(bf16* Wl, const bf16* __restrict__ w, int64_t sm, int M, int K, int mt0, int n_mt,
+                                                      int nk, int tm, int t) {
+  constexpr int WS_ROW = PwRow<bf16>::WS_ROW;
+  const int per = tm * (PW_KC / 8), total = n_mt * nk * per;
+  for (int e = t; e < total; e += 64 * PWW_MW) {
+    const int img = e / per, r = e - img * per, mm = r / (PW_KC / 8), kv = r - mm * (PW_KC / 8);
+    const int mt = img / nk, kc = img - mt * nk;
+    const int m = (mt0 + mt) * tm + mm, k = kc * PW_KC + kv * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < M && k < K) v = *reinterpret_cast<const u32x4*>(w + (int64_t)m * sm + k);
+    *reinterpret_cast<u32x4*>(&Wl[(img * tm + mm) * WS_ROW + kv * 8]) = v;
+  }
+}
 struct PwwOut { bf16* y; const bf16* r; const float* bias; int m; int64_t n; bf16* y2; int split; };
 // output row m: rows past `split` belong to the second output tensor (mi_pw_desc.y_split: two results of one pass over X)
 __device__ __forceinline__ bf16* pww_out_row(const PwwOut& o, int m) {
@@ -798,7 +814,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xres_kernel(PwG q, i
   bf16* const patch = Wl + (int64_t)m_tiles * KB * TM * WS_ROW + wv * PWW_PATCH;
   const int z = blockIdx.z, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
-  if (q.w_direct)
+  if (q.w_direct && q.wb16)
+    pww_stage_weights_b16(Wl, q.wb16 + zb * p.w_bs + zg * p.w_gs, q.wb16_sm, p.m, p.k1 + p.k2, 0, m_tiles, KB, TM, t);
+  else if (q.w_direct)
     pww_stage_weights_f32(Wl, p.w + zb * p.w_bs + zg * p.w_gs, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, 0, m_tiles, KB, TM, t);
   else
     pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice, m_tiles * KB, TM,
@@ -916,7 +934,9 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_stream_kernel(PwG q,
   const int z = bz, zb = z / p.groups, zg = z - zb * p.groups;
   const int wslice = (q.wp_per_batch ? zb : 0) * (q.wp_per_group ? p.groups : 1) + (q.wp_per_group ? zg : 0);
   const int m0 = by * TM;
-  if (q.w_direct)
+  if (q.w_direct && q.wb16)
+    pww_stage_weights_b16(Wl, q.wb16 + zb * p.w_bs + zg * p.w_gs, q.wb16_sm, p.m, p.k1 + p.k2, by, 1, nchunks, TM, t);
+  else if (q.w_direct)
     pww_stage_weights_f32(Wl, p.w + zb * p.w_bs + zg * p.w_gs, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, by, 1, nchunks, TM, t);
   else
     pww_stage_weights(Wl, reinterpret_cast<const bf16*>(q.ws + PW_ZERO_BYTES) + (int64_t)wslice * q.wp_slice +
@@ -1058,7 +1078,8 @@ __global__ __launch_bounds__(64 * PWW_MW) void pw_gemm_wave_xwide_kernel(PwG q, 
   };
   auto w_store = [&](int buf, int sl) {
     if (q.w_direct) {
-      pww_stage_weights_f32(Wl + buf * SLAB, wf, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, sl, 1, KB, SR, t);
+      if (q.wb16) pww_stage_weights_b16(Wl + buf * SLAB, q.wb16 + zb * p.w_bs + zg * p.w_gs, q.wb16_sm, p.m, p.k1 + p.k2, sl, 1, KB, SR, t);
+      else pww_stage_weights_f32(Wl + buf * SLAB, wf, p.w_sm, p.w_sk, p.m, p.k1 + p.k2, sl, 1, KB, SR, t);
       return;
     }
     int tt = t;
@@ -1302,7 +1323,12 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   // MI_PW_DIRECT=1 (A/B switch, off): per-image weights on a wave-owned form without a packed image - the kernels stage them from
   // fp32.  Measured SLOWER (profiles/r02_m_per_image_weights_direct_ab.txt: 165.0 vs 157.2 ms per step): every one of the ~2000
   // workgroups of such a GEMM repeats the scalar fp32 -> bf16 walk that one 7 us pack launch does once.
-  const bool direct = pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && MI_ENV(MI_PW_DIRECT);
+  // Round 4: a producer that also wrote the matrices in bf16 (mi_pw_desc.w_b16) makes the direct staging free - 16-byte copies, as
+  // the packed path's own staging - and the pack launch (183 per training step) goes away.  MI_PW_B16=0 keeps the pack.
+  const bool b16ok = pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && d->w_b16 && aligned16(d->w_b16) &&
+                     d->w_b16_sm % 8 == 0 && d->w_bs % 8 == 0 && d->w_gs % 8 == 0 && (d->k1 + d->k2) % 8 == 0 && !d->f8 &&
+                     !(MI_ENV(MI_PW_B16) && atoi(MI_ENV(MI_PW_B16)) == 0);
+  const bool direct = b16ok || (pl.wave != 0 && d->w_bs != 0 && std::is_same<T, bf16>::value && MI_ENV(MI_PW_DIRECT));
   const unsigned char* cached = direct ? nullptr : pw_cache_lookup(job, pl.bytes, st);
   if (!cached && !direct) {  // re-pack the weights of every slice (and refresh the zero block)
     const int64_t total = (int64_t)pl.m_tiles * pl.k_chunks * pl.tm * PW_KC;
@@ -1319,6 +1345,7 @@ static int pw_launch(const mi_pw_desc* d, const PwK& k, const PwPlan& pl, void* 
   q.f8_sx = d->f8_sx; q.f8_sw = d->f8_sw;
   q.xcd_map = 0;
   q.w_direct = direct ? 1 : 0;
+  q.wb16 = b16ok ? (const bf16*)d->w_b16 : nullptr; q.wb16_sm = d->w_b16_sm;
   if (d->y_split) {
     MI_CHECK_ARG(pl.wave != 0 && (std::is_same<T, bf16>::value), "pw_gemm: a split output needs a wave-owned bf16 form (mi_pw_gemm_split_ok)");
     MI_CHECK_ARG(d->y2 && !d->r && d->y_split > 0 && d->y_split < d->m && aligned16(d->y2) && d->y2_bs % 8 == 0 && d->y2_gs % 8 == 0,

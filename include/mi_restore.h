@@ -144,6 +144,12 @@ typedef struct {
    * results of ONE pass over X (the q and k gradients of MDTA, which multiply the same q, k planes with two per-image
    * matrices).  No residual; only where mi_pw_gemm_split_ok() says so (the wave-owned bf16 kernels); zero = off. */
   int y_split; void* y2; int64_t y2_bs, y2_gs;
+  /* Optional bf16 copy of PER-IMAGE weights (w_bs != 0): the same matrix values as `w`, already rounded to bf16, row-major
+   * [m][k] with unit k stride and row stride w_b16_sm (elements), batch / group strides w_bs / w_gs as for `w` (all multiples of
+   * 8, 16-byte aligned).  The wave-owned bf16 kernels then stage the weights straight from it and no pack launch runs (the
+   * producers of such matrices - the c x c attention fold, the q / k gradient matrices - write both).  `w` must stay valid: the
+   * other kernel forms pack from it.  NULL = off. */
+  const void* w_b16; int64_t w_b16_sm;
 } mi_pw_desc;
 size_t mi_pw_gemm_workspace(const mi_pw_desc* d);
 int mi_pw_gemm(const mi_pw_desc* d, void* ws, void* stream);

@@ -80,16 +80,26 @@ def mdta():
     """Fused pass A (LN -> qkv -> dw3x3 -> q k^T partials + v) + partial sum + fold + M v, against the unfused chain
     (qkv GEMM with LN on load, dw3x3, streaming Gram, fold, M v)."""
     import image_restoration_amd as m
-    for C, heads, H, W in ((48, 1, 256, 256), (96, 2, 128, 128), (96, 1, 256, 256)):
+    shapes = ((48, 1, 256, 256), (96, 2, 128, 128), (96, 1, 256, 256))
+    if os.environ.get("BF_DEEP"):                         # the levels the fused pass does not cover: the chain's own numbers
+        shapes = shapes + ((192, 4, 64, 64), (384, 8, 32, 32))
+    for C, heads, H, W in shapes:
         torch.manual_seed(0)
         x = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16)
         ln_w = 1 + 0.1 * torch.randn(C, device=DEV)
         ln_b = 0.1 * torch.randn(C, device=DEV)
         att = (torch.ones(heads, 1, 1, device=DEV), torch.randn(3 * C, C, 1, 1, device=DEV) / C ** 0.5, None,
                torch.randn(3 * C, 1, 3, 3, device=DEV) / 3, None, torch.randn(C, C, 1, 1, device=DEV) / C ** 0.5, None)
+        chain = lambda: ops.mdta_fwd(x, x, att, heads, False, ln=(ln_w, ln_b, False)) if ops.mdta_fwd_ln_ok(x, heads, 3) else \
+            ops.mdta_fwd(ops.ln_fwd(x, ln_w, ln_b, True, want_stats=False)[0] if False else ops.ln_fwd(x, ln_w, ln_b, True)[0], x, att, heads, False)
+        if not ops.mdta_fused_ok(x, heads, 3):
+            N = float(B) * H * W
+            tc = timeit(chain)
+            print(f"mdta fwd C={C} heads={heads} {H}x{W} bs={B}: no fused kernel (tiles of 8 x 32 per CU: {B * (H // 8) * (W // 32) / 256:.1f}); "
+                  f"chain {tc:8.1f} us = {2.0 * N * (4.0 * C * C + 2.0 * C * (C / heads) + 27.0 * C) / tc / 1e6:6.1f} TF/s over the half-block", flush=True)
+            continue
         pack = ops.mdta_fused_pack(x, heads, ln_w, ln_b, att)
         fused = lambda: ops.mdta_fused_fwd(x, pack, att, heads, True, x)
-        chain = lambda: ops.mdta_fwd(x, x, att, heads, False, ln=(ln_w, ln_b, False))
         if os.environ.get("BF_ABLATE"):
             for name, flag in (("full", 0), ("no GEMM1", 32), ("no conv", 64), ("no Gram", 128), ("no GEMM1/conv", 96),
                                ("prologue + LN only", 224)):
