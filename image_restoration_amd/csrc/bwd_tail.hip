@@ -149,6 +149,8 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       if (lim >= 0) {
         const bf16* base = a.dy + ((int64_t)b * a.M + m0 + 16 * j) * a.N + p0;
         const unsigned off = (unsigned)(rl < lim ? rl : lim) * un + 8u * (ln & 3);
+        // (default cache policy: the two 32-pixel halves of a tile share 128-byte lines - non-temporal loads fetched them twice,
+        //  22.4 -> 27.0 ms per step; the LDS-DMA loads of x / dres measured neutral: profiles/r04_d_nontemporal_ab.txt)
         R[j] = *reinterpret_cast<const u32x4*>(base + off);
       }
     }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     bf16* const ob = a.dx + (int64_t)b * C * a.N + p0 + (unsigned)c0 * un + 4u * q;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-      *reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un) = *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64);
+      MI_STREAM_ST(reinterpret_cast<u32x2*>(ob + (unsigned)(NT / 16 * i) * un), *reinterpret_cast<const u32x2*>(src + NT / 16 * i * 64));
   };
 
   // Tile loop, software-pipelined across tiles: the LayerNorm phase and the dx store of tile i-1 run inside tile i, between the

@@ -134,6 +134,29 @@ __device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return to_f32(*p); }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = Cvt<T>::from(v); }
 
+// Cache policy of the once-read plane accesses (the Vec loads below, the row loads of dwstream.hip, the X / residual loads of
+// pw_gemm.hip).  Non-temporal LOADS: measured per kernel at bs 32 (profiles/r04_d_nontemporal_ab.txt): dwconv_gate_fwd -7.6 %,
+// pw_gemm -1.4 %, LayerNorm -4..-9 %, mdta_av -6 %; the kernels whose operands other workgroups re-read (gram +12 %, bwd_tail
+// +20 %) keep the default policy and do not use these macros.  Non-temporal STORES measured neutral (-DMI_NT_ST for the A/B).
+#ifndef MI_NT_ST
+#define MI_NT_ST 1
+#endif
+#if MI_NT_ST
+#define MI_STREAM_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define MI_STREAM_ST(ptr, val) (*(ptr) = (val))
+#endif
+#ifndef MI_NT_LD
+#define MI_NT_LD 1
+#endif
+#if MI_NT_LD
+#define MI_STREAM_LD(ptr) __builtin_nontemporal_load(ptr)
+#define MI_STREAM_DMA_AUX 2
+#else
+#define MI_STREAM_LD(ptr) (*(ptr))
+#define MI_STREAM_DMA_AUX 0
+#endif
+
 // Vector access of V consecutive elements (V*sizeof(T) in {4,8,16} bytes, pointer aligned to it).
 template <typename T, int V> struct Vec;
 template <> struct Vec<float, 1> {
@@ -150,10 +173,10 @@ template <> struct Vec<float, 2> {
 };
 template <> struct Vec<float, 4> {
   static __device__ __forceinline__ void ld(const float* p, float* o) {
-    f32x4 t = *reinterpret_cast<const f32x4*>(p); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+    f32x4 t = MI_STREAM_LD(reinterpret_cast<const f32x4*>(p)); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
   }
   static __device__ __forceinline__ void st(float* p, const float* v) {
-    f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t;
+    f32x4 t = {v[0], v[1], v[2], v[3]}; MI_STREAM_ST(reinterpret_cast<f32x4*>(p), t);
   }
 };
 template <> struct Vec<bf16, 1> {
@@ -169,7 +192,7 @@ template <> struct Vec<bf16, 2> {
 };
 template <> struct Vec<bf16, 4> {
   static __device__ __forceinline__ void ld(const bf16* p, float* o) {
-    u32x2 t = *reinterpret_cast<const u32x2*>(p);
+    u32x2 t = MI_STREAM_LD(reinterpret_cast<const u32x2*>(p));
     o[0] = bf16_bits_to_f32(t[0] & 0xffffu); o[1] = bf16_bits_to_f32(t[0] >> 16);
     o[2] = bf16_bits_to_f32(t[1] & 0xffffu); o[3] = bf16_bits_to_f32(t[1] >> 16);
   }
@@ -177,12 +200,12 @@ template <> struct Vec<bf16, 4> {
     u32x2 t;
 #pragma unroll
     for (int i = 0; i < 2; ++i) t[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
-    *reinterpret_cast<u32x2*>(p) = t;
+    MI_STREAM_ST(reinterpret_cast<u32x2*>(p), t);
   }
 };
 template <> struct Vec<bf16, 8> {
   static __device__ __forceinline__ void ld(const bf16* p, float* o) {
-    u32x4 t = *reinterpret_cast<const u32x4*>(p);
+    u32x4 t = MI_STREAM_LD(reinterpret_cast<const u32x4*>(p));
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); o[2 * i + 1] = bf16_bits_to_f32(t[i] >> 16); }
   }
@@ -190,7 +213,7 @@ template <> struct Vec<bf16, 8> {
     u32x4 t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
-    *reinterpret_cast<u32x4*>(p) = t;
+    MI_STREAM_ST(reinterpret_cast<u32x4*>(p), t);
   }
 };
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
   if (a.bias) { b1 = a.bias[cc]; if (GATE) b2 = a.bias[cc + a.hidden]; }
   const int yend = min(u.y0 + band_rows, a.H);      // rows [y0, yend) are this unit's outputs
   auto ld = [&](const T* base, int y) -> RV {
-    return (u.active && y >= 0 && y <= yend && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+    return (u.active && y >= 0 && y <= yend && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   float p0[6], p1[6], p2[6], q0[GATE ? 6 : 1], q1[GATE ? 6 : 1], q2[GATE ? 6 : 1], v[4];
   RV c1[PF], c2[GATE ? PF : 1];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
   for (int i = 0; i < 9; ++i) wf[i] = a.w[(int64_t)cc * 9 + 8 - i];
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   float p0[6], p1[6], p2[6], v[4], acc[10];
 #pragma unroll
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
   for (int i = 0; i < 9; ++i) { w1[i] = a.w[(int64_t)j * 9 + 8 - i]; w2[i] = a.w[(int64_t)(j + h) * 9 + 8 - i]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   // one row of (dg, y1, y2) -> window rows of d1 and d2
   auto gate_row = [&](const RV& rdg, const RV& ry1, const RV& ry2, float* r1, float* r2) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
   if (a.bias) { bias2[0] = a.bias[j]; bias2[1] = a.bias[j + h]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   f32x2 hA[6], hB[6], hC[6];            // x rows rho-1, rho, rho+1
   f32x2 p0[6], p1[6], p2[6];            // (d1, d2) rows y-1, y, y+1
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void dws_gate_fwd2_kernel(DwArgs a, int planes
   if (a.bias) { bias2[0] = a.bias[cc]; bias2[1] = a.bias[cc + h]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y) -> RV {
-    return (u.active && y >= 0 && y <= yend && y < a.H) ? *reinterpret_cast<const RV*>(base + (int64_t)y * a.W) : R::zero();
+    return (u.active && y >= 0 && y <= yend && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   auto pair_row = [&](const RV& r1, const RV& r2, f32x2* out6) {
     float v1[4], v2[4];

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
     for (int v = 0; v < XV; ++v) {
       const int64_t nn = n + v * EPVX;
       if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPVX == 0 for every row, so the vector is all-in or all-out
-        xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
+        xreg[v] = MI_STREAM_LD(reinterpret_cast<const u32x4*>(row + nn));
       } else {
         __attribute__((aligned(16))) T tmp[EPVX];
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, in
     for (int c = 0; c < PWR_MAXC; ++c) {
       const int k = c * PW_KC + xr_row;
       const T* row = k < p.k1 ? x1 + (int64_t)k * p.n : x2 + (int64_t)(k - p.k1) * p.n;
-      r[c] = (in && c < nchunks && k < ktot) ? *reinterpret_cast<const u32x4*>(row + n) : zero4;
+      r[c] = (in && c < nchunks && k < ktot) ? MI_STREAM_LD(reinterpret_cast<const u32x4*>(row + n)) : zero4;
     }
   };
   // epilogue geometry: lane reads row (it*8 + lane/8) of its wave's 16-row slab, 8 pixels at (lane%8)*8
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void pw_gemm_res_kernel(PwG q, int n_tiles, in
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int m = m0 + mw + 16 * mf + it * 8 + e_row;
-        r[mf][it] = (rz && mf < nfr && tile < n_tiles && m < p.m && n < p.n) ? *reinterpret_cast<const u32x4*>(rz + (int64_t)m * p.n + n) : zero4;
+        r[mf][it] = (rz && mf < nfr && tile < n_tiles && m < p.m && n < p.n) ? MI_STREAM_LD(reinterpret_cast<const u32x4*>(rz + (int64_t)m * p.n + n)) : zero4;
       }
   };
 
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwG q) {
         if (k < p.k1) src = reinterpret_cast<const unsigned char*>(x1 + (int64_t)k * p.n + n);
         else if (k < ktot) src = reinterpret_cast<const unsigned char*>(x2 + (int64_t)(k - p.k1) * p.n + n);
       }
-      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, MI_STREAM_DMA_AUX);
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -578,7 +578,7 @@ __device__ __forceinline__ void pww_load_chunk(u32x4 (&raw)[4], const PwwX& x, i
     const int k = kb * PW_KC + 8 * i + (lane >> 3);
     const int kc = k < x.ktot ? k : 0;          // rows past K read row 0 and are zeroed on the way into the patch
     const bf16* row = kc < x.k1 ? x.x1 + (int64_t)kc * x.n : x.x2 + (int64_t)(kc - x.k1) * x.n;
-    raw[i] = *reinterpret_cast<const u32x4*>(row + n0 + 8 * (lane & 7));
+    raw[i] = MI_STREAM_LD(reinterpret_cast<const u32x4*>(row + n0 + 8 * (lane & 7)));
   }
 }
 // chunk -> patch -> MFMA A operands (same k-slot order as pw_chunk_mma: element j<4 of lane group g is k = 4g+j, j>=4 is 16+4g+j-4)
@@ -664,7 +664,7 @@ __device__ __forceinline__ void pww_load_res(u32x4 (&rr)[2], const PwwOut& o, in
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int m = mbase + it * 8 + (lane >> 3);
-    rr[it] = (o.r && m < o.m) ? *reinterpret_cast<const u32x4*>(o.r + (int64_t)m * o.n + n0 + 8 * (lane & 7)) : zero4;
+    rr[it] = (o.r && m < o.m) ? MI_STREAM_LD(reinterpret_cast<const u32x4*>(o.r + (int64_t)m * o.n + n0 + 8 * (lane & 7))) : zero4;
   }
 }
 // one 16-channel accumulator fragment (four pixel fragments) -> fp32 slab in the wave's patch -> + bias + residual -> 128-byte rows
@@ -720,7 +720,7 @@ __device__ __forceinline__ void pww_store_bf16(const f32x4 (&acc0)[4], const f32
   for (int it = 0; it < 2 * NFR; ++it) {
     const int row = it * 8 + e_row;
     const u32x4 v = *reinterpret_cast<const u32x4*>(&patch[row * PWW_XS + e_col]);
-    if (mbase + row < o.m) *reinterpret_cast<u32x4*>(pww_out_row(o, mbase + row) + n0 + e_col) = v;
+    if (mbase + row < o.m) MI_STREAM_ST(reinterpret_cast<u32x4*>(pww_out_row(o, mbase + row) + n0 + e_col), v);
   }
   wave_lds_sync();
 }
