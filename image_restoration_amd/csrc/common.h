@@ -55,7 +55,7 @@ template <> struct MfmaOp<true> {
 // tests and A/B tools that flip a switch inside one process; call it with no launch planner running on another thread.
 #define MI_ENV_LIST(X)                                                                                                       \
   X(MI_BT_WIDE) X(MI_BT_DEBUG) X(MI_DW_LDS) X(MI_FG_CFG) X(MI_FG_DEBUG) X(MI_FG_NOXCD) X(MI_GRAM_FOLD) X(MI_GRAM_WANT)      \
-  X(MI_GRAM_RECT) X(MI_GRAM_LDS) X(MI_GRAM_STREAM_ALL) X(MI_LN_FORM) X(MI_LN_BWD384) X(MI_CO_STREAM) X(MI_ATTN_DQK_SPLIT)    \
+  X(MI_GRAM_RECT) X(MI_GRAM_LDS) X(MI_GRAM_STREAM_ALL) X(MI_LN_FORM) X(MI_CO_STREAM) X(MI_ATTN_DQK_SPLIT)    \
   X(MI_PW_DMA) X(MI_PW_TM_EVEN) X(MI_PW_WAVE) X(MI_PW_CHUNKED) X(MI_PW_XWIDE) X(MI_PW_WAVE_WIDE) X(MI_PW_DIRECT)             \
   X(MI_PW_WAVE_TPW) X(MI_PW_XCD) X(MI_PW_TPB) X(MI_PW_B16) X(MI_FM_DEBUG) X(MI_FM_CFG) X(MI_NO_FUSED_MDTA) X(MI_NO_PW_LDS) X(MI_PW_LDS)
 enum EnvId {
