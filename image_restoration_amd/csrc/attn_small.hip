@@ -20,114 +20,146 @@ static inline int attn_ld(int c) { return c + 1; }
 static inline int attn_ct(int c) { return (c + 15) / 16; }
 static inline int attn_rchunks(int C) { return (C + ATT_RC - 1) / ATT_RC; }
 
-// cosine, temperature, row softmax of one (image, head) into LDS As[c][ld]; optionally stored to global P/A/nrm
-// (All global reads of a thread are issued before the first is used: written as `for (e = t; e < c*c; e += 256)` the
-// loop took one HBM/L2 round trip per element - 36 in a row at c = 96 - and these kernels ran 40-70 us on KB-sized data.)
-template <int CT>
-__device__ __forceinline__ void attn_softmax_to_lds(float* As, int ld, const float* __restrict__ gz,
-                                                    const float* __restrict__ sz, float temp, int c, float* P, float* A,
-                                                    float* nrm) {
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (nrm)
-    for (int e = t; e < 2 * c; e += 256) nrm[e] = fmaxf(sqrtf(sz[e]), NORM_EPS);
-  float gv[CT * CT], sq[CT * CT], sk[CT * CT];
-#pragma unroll
-  for (int it = 0; it < CT * CT; ++it) {
-    const int e = t + 256 * it;
-    const bool in = e < c * c;
-    const int i = in ? e / c : 0, j = in ? e - i * c : 0;
-    gv[it] = in ? gz[e] : 0.f;
-    sq[it] = sz[i];
-    sk[it] = sz[c + j];
-  }
-#pragma unroll
-  for (int it = 0; it < CT * CT; ++it) {
-    const int e = t + 256 * it;
-    if (e < c * c) {
-      const int i = e / c, j = e - i * c;
-      const float nq = fmaxf(sqrtf(sq[it]), NORM_EPS), nk = fmaxf(sqrtf(sk[it]), NORM_EPS);
-      const float pv = gv[it] / (nq * nk);
-      if (P) P[e] = pv;
-      As[i * ld + j] = pv * temp;
-    }
-  }
-  __syncthreads();
-  for (int i = wv; i < c; i += 4) {
-    float mx = -INFINITY;
-    for (int j = lane; j < c; j += 64) mx = fmaxf(mx, As[i * ld + j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < c; j += 64) {
-      const float ev = expf(As[i * ld + j] - mx);
-      As[i * ld + j] = ev;
-      sum += ev;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < c; j += 64) {
-      const float av = As[i * ld + j] * inv;
-      As[i * ld + j] = av;
-      if (A) A[i * c + j] = av;
-    }
-  }
-  __syncthreads();
+// All-reduce over the 16 lanes of a DPP row (xor-1, xor-2 inside the quad, half-row mirror, row mirror): every lane ends up
+// with the row's result, no LDS-pipe permutes and no readlane.
+#define MI_ROW16_STEP(OP, ctrl)                                                                                    \
+  v = OP(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                  ctrl, 0xf, 0xf, true)))
+__device__ __forceinline__ float row16_sum(float v) {
+#define MI_ADDF(a, b) ((a) + (b))
+  MI_ROW16_STEP(MI_ADDF, 0xB1); MI_ROW16_STEP(MI_ADDF, 0x4E); MI_ROW16_STEP(MI_ADDF, 0x141); MI_ROW16_STEP(MI_ADDF, 0x140);
+#undef MI_ADDF
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  MI_ROW16_STEP(fmaxf, 0xB1); MI_ROW16_STEP(fmaxf, 0x4E); MI_ROW16_STEP(fmaxf, 0x141); MI_ROW16_STEP(fmaxf, 0x140);
+  return v;
+}
+#undef MI_ROW16_STEP
+
+// LDS floats of attn_fold_kernel<CT> with rpw row chunks of W_o per workgroup
+static inline size_t attn_fold_lds_floats(int ct, int rpw) {
+  const size_t cp = 16 * (size_t)ct;
+  return cp * (cp + 1) + 2 * cp + (size_t)rpw * ATT_RC * (cp + 1);
 }
 
-// forward: grid (Z, C/16).  Every workgroup redoes the (cheap) c x c softmax of its (image, head) in LDS and folds 16
-// rows of W_o:  M[b][r][h*c+j] = sum_i W_o[r][h*c+i] A[i][j].  Row-chunk 0 also stores P, A and the norms.
+// forward: grid (Z, ceil(C/16 / rpw)).  Every workgroup redoes the c x c cosine / temperature / row softmax of its (image, head)
+// and folds rpw chunks of 16 rows of W_o:  M[b][r][h*c+j] = sum_i W_o[r][h*c+i] A[i][j].  The workgroups of row group 0 also
+// store P, A and the norms.
+//  * softmax: a 16-lane DPP row owns a matrix row (lane l16 holds columns l16 + 16 q), 16 matrix rows per pass, CT passes; all
+//    global loads are issued up front, max / sum are 4-step DPP all-reduces, the 2c inverse norms come from LDS.  (The first
+//    form - one wave per row, integer divisions to find (i, j), three sqrt / div per element - took 29 us at c = 96 and 57 us
+//    at C = 384 where 24 row chunks each redid it: profiles/r04_f_attn_small.txt.)
+//  * fold: fp32 MFMA (16x16x4): a wave owns 16 x 16 output tiles, both operands read from LDS one float per lane and step.
 template <int CT>
 __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict__ graw, const float* __restrict__ ss,
                                                         const float* __restrict__ temperature, const float* __restrict__ wo,
                                                         float* __restrict__ P, float* __restrict__ A, float* __restrict__ nrm,
                                                         float* __restrict__ M, bf16* __restrict__ Mb, bf16* __restrict__ Mtb, int C,
-                                                        int heads, int ld) {
+                                                        int heads, int rpw) {
+  constexpr int CP = 16 * CT, LD = CP + 1;
   extern __shared__ float sm[];
+  float* As = sm;                       // [CP][LD]; rows and columns >= c are zero
+  float* inr = As + CP * LD;            // [2 CP] 1 / max(|q_i|, eps), 1 / max(|k_j|, eps)
+  float* Wt = inr + 2 * CP;             // [rpw * 16][LD]; columns >= c and rows >= C are zero
   const int c = C / heads;
-  float* As = sm;               // [c][ld]
-  float* Wt = As + c * ld;      // [RC][c]
   const int z = blockIdx.x, b = z / heads, h = z - b * heads;
-  const int r0 = blockIdx.y * ATT_RC;
-  const int t = threadIdx.x, tr = t >> 4, tj = t & 15;
-  {
-    float wv_[CT];
-#pragma unroll
-    for (int it = 0; it < CT; ++it) {
-      const int e = t + 256 * it;
-      const int rr = e / c, col = e - rr * c;
-      wv_[it] = (e < ATT_RC * c && r0 + rr < C) ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < CT; ++it) {
-      const int e = t + 256 * it;
-      if (e < ATT_RC * c) Wt[e] = wv_[it];
-    }
-  }
+  const int rch = (C + ATT_RC - 1) / ATT_RC;
+  const int rc0 = blockIdx.y * rpw;
+  const int nrc = rch - rc0 < rpw ? rch - rc0 : rpw;     // row chunks of this workgroup
+  const int t = threadIdx.x, l16 = t & 15, g16 = t >> 4;
   const bool first = blockIdx.y == 0;
-  attn_softmax_to_lds<CT>(As, ld, graw + (int64_t)z * c * c, ss + (int64_t)z * 2 * c, temperature[h], c,
-                      first ? P + (int64_t)z * c * c : nullptr, first ? A + (int64_t)z * c * c : nullptr,
-                      first ? nrm + (int64_t)z * 2 * c : nullptr);
-  float acc[CT];
+  const float* gz = graw + (int64_t)z * c * c;
+  const float* sz = ss + (int64_t)z * 2 * c;
+
+  float gv[CT][CT];
 #pragma unroll
-  for (int q = 0; q < CT; ++q) acc[q] = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < c; ++i) {
-    const float w = Wt[tr * c + i];
+  for (int it = 0; it < CT; ++it) {
+    const int i = g16 + 16 * it;
 #pragma unroll
     for (int q = 0; q < CT; ++q) {
-      const int j = tj + 16 * q;
-      if (j < c) acc[q] += w * As[i * ld + j];
+      const int j = l16 + 16 * q;
+      gv[it][q] = (i < c && j < c) ? gz[i * c + j] : 0.f;
     }
   }
-  const int r = r0 + tr;
-  if (r < C) {
+  for (int e = t; e < nrc * ATT_RC * CP; e += 256) {
+    const int rr = e / CP, col = e - rr * CP, r = rc0 * ATT_RC + rr;
+    Wt[rr * LD + col] = (r < C && col < c) ? wo[(int64_t)r * C + h * c + col] : 0.f;
+  }
+  for (int e = t; e < 2 * CP; e += 256) {
+    const int k = e < CP ? e : e - CP;
+    float v = 0.f;
+    if (k < c) {
+      const float n = fmaxf(sqrtf(sz[(e < CP ? 0 : c) + k]), NORM_EPS);
+      if (first) nrm[(int64_t)z * 2 * c + (e < CP ? 0 : c) + k] = n;
+      v = 1.0f / n;
+    }
+    inr[e] = v;
+  }
+  __syncthreads();
+  const float temp = temperature[h];
+  float* Pz = P + (int64_t)z * c * c;
+  float* Az = A + (int64_t)z * c * c;
+#pragma unroll
+  for (int it = 0; it < CT; ++it) {
+    const int i = g16 + 16 * it;
+    const bool rok = i < c;
+    const float iq = inr[i];
+    float sv[CT], mx = -INFINITY;
 #pragma unroll
     for (int q = 0; q < CT; ++q) {
-      const int j = tj + 16 * q;
-      if (j < c) {
-        M[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = acc[q];
-        // bf16 copies for the per-image-weight GEMMs (mi_pw_desc.w_b16): M_b for out = M_b v, its transpose for dv = M_b^T dy
-        if (Mb) Mb[(int64_t)b * C * C + (int64_t)r * C + h * c + j] = (bf16)acc[q];
-        if (Mtb) Mtb[(int64_t)b * C * C + (int64_t)(h * c + j) * C + r] = (bf16)acc[q];
+      const int j = l16 + 16 * q;
+      const float pv = gv[it][q] * iq * inr[CP + j];
+      if (first && rok && j < c) Pz[i * c + j] = pv;
+      sv[q] = (j < c || !rok) ? pv * temp : -INFINITY;     // (padding rows: all zeros, kept finite)
+      mx = fmaxf(mx, sv[q]);
+    }
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < CT; ++q) { sv[q] = __expf(sv[q] - mx); sum += sv[q]; }
+    sum = row16_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+      const int j = l16 + 16 * q;
+      const bool in = rok && j < c;
+      const float av = in ? sv[q] * inv : 0.f;
+      As[i * LD + j] = av;
+      if (first && in) Az[i * c + j] = av;
+    }
+  }
+  __syncthreads();
+
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const bool tb_vec = (C & 3) == 0;
+  for (int tile = wv; tile < nrc * CT; tile += 4) {
+    const int rr = tile / CT, nt = tile - rr * CT;
+    const float* wp = Wt + (rr * ATT_RC + li) * LD + kq;
+    const float* ap = As + kq * LD + 16 * nt + li;
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < CP / 4; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[4 * ks], ap[4 * ks * LD], d, 0, 0, 0);
+    // lane holds M[r .. r + 3][h c + j],  r = 16 (rc0 + rr) + 4 kq,  j = 16 nt + li
+    const int r = (rc0 + rr) * ATT_RC + 4 * kq, j = 16 * nt + li;
+    if (j < c) {
+      const int64_t mb = (int64_t)b * C * C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (r + i < C) {
+          M[mb + (int64_t)(r + i) * C + h * c + j] = d[i];
+          // bf16 copies for the per-image-weight GEMMs (mi_pw_desc.w_b16): M_b for out = M_b v, its transpose for dv = M_b^T dy
+          if (Mb) Mb[mb + (int64_t)(r + i) * C + h * c + j] = (bf16)d[i];
+        }
+      if (Mtb) {
+        bf16* tp = Mtb + mb + (int64_t)(h * c + j) * C + r;
+        if (tb_vec && r + 3 < C) {
+          *reinterpret_cast<u32x2*>(tp) = (u32x2){cvt_pk_bf16(d[0], d[1]), cvt_pk_bf16(d[2], d[3])};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (r + i < C) tp[i] = (bf16)d[i];
+        }
       }
     }
   }
@@ -436,15 +468,20 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
                      float* nrm, float* M, int B, int C, int heads, hipStream_t st, void* Mb, void* Mtb) {
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
-  const int ld = attn_ld(c);
-  const size_t lds = ((size_t)c * ld + ATT_RC * c) * sizeof(float);
-  dim3 grid(B * heads, attn_rchunks(C));
+  MI_CHECK_ARG(graw && ss && temperature && wo && P && A && nrm && M, "mdta: null pointer in the attention fold");
+  // row chunks per workgroup: every workgroup redoes the softmax, so deep levels (many heads, many chunks) fold several chunks
+  // each; about 768 workgroups (3 per CU) are kept
+  const int Z = B * heads, rch = attn_rchunks(C);
+  int rpw = (int)(((int64_t)Z * rch) / 768);
+  rpw = rpw < 1 ? 1 : (rpw > rch ? rch : (rpw > 8 ? 8 : rpw));
+  dim3 grid(Z, cdiv(rch, rpw));
   ProfScope ps(st, K_ATTN_FOLD, 4.0 * B * (3.0 * C * c + 2.0 * C * C), 2.0 * B * C * (double)c * C);
   ATTN_CT_SWITCH(attn_ct(c), {
+    const size_t lds = attn_fold_lds_floats(CT, rpw) * sizeof(float);
     if (lds > 64 * 1024)
       MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fold_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((attn_fold_kernel<CT>), grid, dim3(256), lds, st, graw, ss, temperature, wo, P, A, nrm, M, (bf16*)Mb, (bf16*)Mtb, C,
-                       heads, ld);
+                       heads, rpw);
   });
   MI_LAUNCH_CHECK();
   return MI_OK;
