@@ -165,228 +165,226 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
   }
 }
 
-// backward, stage 1: grid (Z, C/16).  For its 16 rows r of W_o and dM (column block of head h):
-//   dA_part[z][chunk][i][j] = sum_r W_o[r][h*c+i] dM[r][h*c+j]      (thread tile CT x CT)
-//   dWo_part[b][r][h*c+i]   = sum_j dM[r][h*c+j] A[i][j]
+// backward of the c x c side, one launch: grid (Z, 1 + ceil(C / 64)).
+//  y == 0: dA = W_o[:, head]^T dM[:, head] over all C rows (fp32 MFMA, both operands staged through LDS in chunks of 32 rows), then in
+//          registers: softmax backward dS = A (dA - rowdot), d temperature, and the per-image weights of the gradient GEMM(s)
+//          dq = G1 k + D1 q,  dk = G1^T q + D2 k  with G1 = temperature dS/(|q_i||k_j|), D1_i = -sum_j dS_ij S_ij/|q_i|^2,
+//          D2_j = -sum_i dS_ij S_ij/|k_j|^2, as ONE [2c][2c] matrix per (image, head) acting on the stacked operand [k; q]:
+//            rows 0..c-1  (dq): [ G1    | D1 ]        rows c..2c-1 (dk): [ D2 | G1^T ]
+//          so that both gradients come out of one pass over q and k (mi_pw_desc.y_split), or of two GEMMs over row halves.
+//          Wave w owns the row blocks mt = w, w + 4 of dA (all their column tiles): row sums are 16-lane DPP all-reduces.
+//  y >= 1: 64 rows of dW_o:  dWo_part[b][r][h*c+i] = sum_j dM[r][h*c+j] A[i][j]   (fp32 MFMA, 16 rows per wave).
+// (The first form - a partial kernel per 16-row chunk writing c x c partials of dA, CT x CT outer products on the VALU, and a
+//  finishing kernel summing them - took 65 us at c = 96 and 67 us at C = 384: profiles/r04_f_attn_small.txt.)
+constexpr int ATT_KR = 32;    // rows of W_o / dM per staged chunk (y == 0)
+constexpr int ATT_RW = 64;    // rows of dW_o per workgroup (y >= 1)
+static inline size_t attn_bwd_lds_floats(int ct) {
+  const size_t cp = 16 * (size_t)ct, ld = cp + 1;
+  const size_t r0 = 2 * ATT_KR * ld + 16 * cp + 2 * cp + 8, r1 = cp * ld + ATT_RW * ld;
+  return r0 > r1 ? r0 : r1;
+}
 template <int CT>
-__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(const float* __restrict__ dM, const float* __restrict__ A,
-                                                               const float* __restrict__ wo, float* __restrict__ dA_part,
-                                                               float* __restrict__ dwo_part, int C, int heads, int ld) {
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ dM, const float* __restrict__ A,
+                                                       const float* __restrict__ P, const float* __restrict__ nrm,
+                                                       const float* __restrict__ temperature, const float* __restrict__ wo,
+                                                       float* __restrict__ dwo_part, float* __restrict__ dtemp_part,
+                                                       float* __restrict__ wd, bf16* __restrict__ wdb, int C, int heads) {
+  constexpr int CP = 16 * CT, LD = CP + 1, MB = (CT + 3) / 4;
   extern __shared__ float sm[];
   const int c = C / heads;
-  float* As = sm;                  // [c][ld]
-  float* Wt = As + c * ld;         // [RC][c]
-  float* Dt = Wt + ATT_RC * c;     // [RC][c]
   const int z = blockIdx.x, b = z / heads, h = z - b * heads;
-  const int rc = blockIdx.y, r0 = rc * ATT_RC;
-  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-  const float* dMb = dM + (int64_t)b * C * C;
+  const int t = threadIdx.x, lane = t & 63, li = lane & 15, kq = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const float* dMb = dM + (int64_t)b * C * C + h * c;      // column block of this head
   const float* Az = A + (int64_t)z * c * c;
-  {
-    float wv_[CT], dv_[CT], av_[CT * CT];
-#pragma unroll
-    for (int it = 0; it < CT; ++it) {
-      const int e = t + 256 * it;
-      const int rr = e / c, col = e - rr * c;
-      const bool in = e < ATT_RC * c && r0 + rr < C;
-      wv_[it] = in ? wo[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
-      dv_[it] = in ? dMb[(int64_t)(r0 + rr) * C + h * c + col] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < CT * CT; ++it) {
-      const int e = t + 256 * it;
-      av_[it] = e < c * c ? Az[e] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < CT; ++it) {
-      const int e = t + 256 * it;
-      if (e < ATT_RC * c) { Wt[e] = wv_[it]; Dt[e] = dv_[it]; }
-    }
-#pragma unroll
-    for (int it = 0; it < CT * CT; ++it) {
-      const int e = t + 256 * it;
-      if (e < c * c) { const int i = e / c; As[i * ld + (e - i * c)] = av_[it]; }
-    }
-  }
-  __syncthreads();
-  float acc[CT][CT];
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int q = 0; q < CT; ++q) acc[a][q] = 0.f;
-#pragma unroll 4
-  for (int rr = 0; rr < ATT_RC; ++rr) {
-    float wa[CT], db[CT];
-#pragma unroll
-    for (int a = 0; a < CT; ++a) wa[a] = (ti + 16 * a < c) ? Wt[rr * c + ti + 16 * a] : 0.f;
-#pragma unroll
-    for (int q = 0; q < CT; ++q) db[q] = (tj + 16 * q < c) ? Dt[rr * c + tj + 16 * q] : 0.f;
-#pragma unroll
-    for (int a = 0; a < CT; ++a)
-#pragma unroll
-      for (int q = 0; q < CT; ++q) acc[a][q] += wa[a] * db[q];
-  }
-  float* dAp = dA_part + ((int64_t)z * gridDim.y + rc) * c * c;
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int i = ti + 16 * a, j = tj + 16 * q;
-      if (i < c && j < c) dAp[i * c + j] = acc[a][q];
-    }
-  // dWo rows of this chunk: thread (tr = ti, lanes tj over i)
-  float wacc[CT];
-#pragma unroll
-  for (int q = 0; q < CT; ++q) wacc[q] = 0.f;
-  for (int j = 0; j < c; ++j) {
-    const float d = Dt[ti * c + j];
-#pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int i = tj + 16 * q;
-      if (i < c) wacc[q] += d * As[i * ld + j];
-    }
-  }
-  const int r = r0 + ti;
-  if (r < C) {
-#pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int i = tj + 16 * q;
-      if (i < c) dwo_part[(int64_t)b * C * C + (int64_t)r * C + h * c + i] = wacc[q];
-    }
-  }
-}
 
-// backward, stage 2: grid (Z).  dA = sum of the chunk partials; softmax backward dS = A (dA - rowdot); d temperature;
-// and the per-image weights of the gradient GEMM(s)  dq = G1 k + D1 q,  dk = G1^T q + D2 k  with
-// G1 = temperature dS/(|q_i||k_j|), D1_i = -sum_j dS_ij S_ij/|q_i|^2, D2_j = -sum_i dS_ij S_ij/|k_j|^2,
-// as ONE [2c][2c] matrix per (image, head) acting on the stacked operand [k; q]:
-//   rows 0..c-1  (dq): [ G1    | D1 ]        rows c..2c-1 (dk): [ D2 | G1^T ]
-// so that both gradients come out of one pass over q and k (mi_pw_desc.y_split), or of two GEMMs over row halves.
-template <int CT>
-__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const float* __restrict__ dA_part, int rchunks,
-                                                              const float* __restrict__ A, const float* __restrict__ P,
-                                                              const float* __restrict__ nrm,
-                                                              const float* __restrict__ temperature,
-                                                              float* __restrict__ dtemp_part, float* __restrict__ wd, bf16* __restrict__ wdb,
-                                                              int C, int heads) {
-  __shared__ float colp[16 * ATTN_MAX_C];
-  __shared__ float rqs[ATTN_MAX_C], rks[ATTN_MAX_C], red[4];
-  const int c = C / heads;
-  const int z = blockIdx.x, h = z % heads;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int ti = t >> 4, tj = t & 15;
-  const float temp = temperature[h];
-  const float* Az = A + (int64_t)z * c * c;
-  const float* Pz = P + (int64_t)z * c * c;
-  const float* nz = nrm + (int64_t)z * 2 * c;
-  const float* dAz = dA_part + (int64_t)z * rchunks * c * c;
-  float acc[CT][CT], av[CT][CT];
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int i = ti + 16 * a, j = tj + 16 * q;
-      acc[a][q] = 0.f;
-      av[a][q] = (i < c && j < c) ? Az[i * c + j] : 0.f;
+  if (blockIdx.y > 0) {
+    // ---- rows of dW_o
+    float* As = sm;                 // [CP][LD]  A, zero padded
+    float* Ds = As + CP * LD;       // [RW][LD]  dM rows, zero padded
+    const int r0 = (blockIdx.y - 1) * ATT_RW;
+    for (int e = t; e < CP * CP; e += 256) {
+      const int i = e / CP, j = e - i * CP;
+      As[i * LD + j] = (i < c && j < c) ? Az[i * c + j] : 0.f;
     }
-  float pvv[CT][CT];
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int i = ti + 16 * a, j = tj + 16 * q;
-      pvv[a][q] = (i < c && j < c) ? Pz[i * c + j] : 0.f;
+    for (int e = t; e < ATT_RW * CP; e += 256) {
+      const int rr = e / CP, j = e - rr * CP;
+      Ds[rr * LD + j] = (r0 + rr < C && j < c) ? dMb[(int64_t)(r0 + rr) * C + j] : 0.f;
     }
-  // four chunk partials per step: their loads are independent and go out together (one round trip per four chunks)
-  for (int rc = 0; rc < rchunks; rc += 4) {
-    float t0[CT][CT], t1[CT][CT], t2[CT][CT], t3[CT][CT];
+    __syncthreads();
+    if (r0 + 16 * wv >= C) return;
+    const float* dp = Ds + (16 * wv + li) * LD + kq;
+    f32x4 d[CT];
 #pragma unroll
-    for (int a = 0; a < CT; ++a)
+    for (int nt = 0; nt < CT; ++nt) d[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ks = 0; ks < CP / 4; ++ks) {
+      const float av = dp[4 * ks];
 #pragma unroll
-      for (int q = 0; q < CT; ++q) {
-        const int i = ti + 16 * a, j = tj + 16 * q;
+      for (int nt = 0; nt < CT; ++nt)
+        d[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, As[(16 * nt + li) * LD + 4 * ks + kq], d[nt], 0, 0, 0);
+    }
+    float* op = dwo_part + (int64_t)b * C * C + h * c;
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+      const int i = 16 * nt + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 16 * wv + 4 * kq + r;
+        if (row < C && i < c) op[(int64_t)row * C + i] = d[nt][r];
+      }
+    }
+    return;
+  }
+
+  // ---- dA and everything behind it
+  float* Ws = sm;                      // [KR][LD]
+  float* Ds = Ws + ATT_KR * LD;        // [KR][LD]
+  float* colp = Ds + ATT_KR * LD;      // [16][CP]
+  float* rks = colp + 16 * CP;         // [CP]
+  float* red = rks + 2 * CP;           // [4]
+  const float* wob = wo + h * c;
+  constexpr int NLD = (ATT_KR * CP + 255) / 256;     // staged elements per thread and operand
+  float wr[NLD], dr[NLD];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = t + 256 * u, rr = e / CP, j = e - rr * CP;
+      const bool in = e < ATT_KR * CP && k0 + rr < C && j < c;
+      wr[u] = in ? wob[(int64_t)(k0 + rr) * C + j] : 0.f;
+      dr[u] = in ? dMb[(int64_t)(k0 + rr) * C + j] : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int e = t + 256 * u, rr = e / CP, j = e - rr * CP;
+      if (e < ATT_KR * CP) { Ws[rr * LD + j] = wr[u]; Ds[rr * LD + j] = dr[u]; }
+    }
+  };
+  fetch(0);
+  // A and P in the accumulator layout: rows 16 mt + 4 kq + r, column 16 nt + li
+  float av[MB][CT][4], pv[MB][CT][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * (wv + 4 * mb) + 4 * kq + r, j = 16 * nt + li;
         const bool in = i < c && j < c;
-        const int64_t o = (int64_t)rc * c * c + i * c + j;
-        t0[a][q] = in ? dAz[o] : 0.f;
-        t1[a][q] = (in && rc + 1 < rchunks) ? dAz[o + (int64_t)c * c] : 0.f;
-        t2[a][q] = (in && rc + 2 < rchunks) ? dAz[o + 2 * (int64_t)c * c] : 0.f;
-        t3[a][q] = (in && rc + 3 < rchunks) ? dAz[o + 3 * (int64_t)c * c] : 0.f;
+        av[mb][nt][r] = in ? Az[i * c + j] : 0.f;
+        pv[mb][nt][r] = in ? P[(int64_t)z * c * c + i * c + j] : 0.f;
       }
+  f32x4 acc[MB][CT];
 #pragma unroll
-    for (int a = 0; a < CT; ++a)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int q = 0; q < CT; ++q) acc[a][q] += ((t0[a][q] + t1[a][q]) + t2[a][q]) + t3[a][q];
+    for (int nt = 0; nt < CT; ++nt) acc[mb][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < C; k0 += ATT_KR) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (k0 + ATT_KR < C) fetch(k0 + ATT_KR);
+#pragma unroll
+    for (int ks = 0; ks < ATT_KR / 4; ++ks) {
+      float bv[CT];
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt) bv[nt] = Ds[(4 * ks + kq) * LD + 16 * nt + li];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int mt = wv + 4 * mb;
+        if (mt < CT) {
+          const float a = Ws[(4 * ks + kq) * LD + 16 * mt + li];
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt) acc[mb][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nt], acc[mb][nt], 0, 0, 0);
+        }
+      }
+    }
   }
-  float tsum = 0.f;
-  float colsum[CT];
+  const float temp = temperature[h];
+  const float* nz = nrm + (int64_t)z * 2 * c;
+  float tsum = 0.f, colsum[CT], rq[MB][4];
 #pragma unroll
-  for (int q = 0; q < CT; ++q) colsum[q] = 0.f;
+  for (int nt = 0; nt < CT; ++nt) colsum[nt] = 0.f;
 #pragma unroll
-  for (int a = 0; a < CT; ++a) {
-    const int i = ti + 16 * a;
-    float dot = 0.f;
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int q = 0; q < CT; ++q) dot += acc[a][q] * av[a][q];
+    for (int r = 0; r < 4; ++r) {
+      float dot = 0.f;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-    float rqa = 0.f;
+      for (int nt = 0; nt < CT; ++nt) dot += acc[mb][nt][r] * av[mb][nt][r];
+      dot = row16_sum(dot);
+      float rqa = 0.f;
 #pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int j = tj + 16 * q;
-      float ds = 0.f;
-      if (i < c && j < c) {
-        ds = av[a][q] * (acc[a][q] - dot);
-        const float pv = pvv[a][q];
-        tsum += ds * pv;
-        rqa += ds * pv * temp;
-        colsum[q] += ds * pv * temp;
+      for (int nt = 0; nt < CT; ++nt) {
+        const float ds = av[mb][nt][r] * (acc[mb][nt][r] - dot);      // (zero outside the c x c block: av is)
+        const float sp = ds * pv[mb][nt][r];
+        tsum += sp;
+        rqa += sp * temp;
+        colsum[nt] += sp * temp;
+        acc[mb][nt][r] = ds;
       }
-      acc[a][q] = ds;
+      rq[mb][r] = row16_sum(rqa);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) rqa += __shfl_xor(rqa, o, 64);
-    if (tj == 0 && i < c) rqs[i] = rqa;
-  }
-#pragma unroll
-  for (int q = 0; q < CT; ++q) {
-    const int j = tj + 16 * q;
-    if (j < c) colp[ti * c + j] = colsum[q];
-  }
+  for (int nt = 0; nt < CT; ++nt) colp[(4 * wv + kq) * CP + 16 * nt + li] = colsum[nt];
   tsum = wave_sum(tsum);
   if (lane == 0) red[wv] = tsum;
   __syncthreads();
   if (t == 0) dtemp_part[z] = (red[0] + red[1]) + (red[2] + red[3]);
-  for (int j = t; j < c; j += 256) {
+  for (int j = t; j < CP; j += 256) {
     float s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s2 += colp[k * c + j];
+    for (int k = 0; k < 16; ++k) s2 += colp[k * CP + j];
     rks[j] = s2;
   }
   __syncthreads();
   float* wq = wd + (int64_t)z * 2 * c * 2 * c;     // rows of dq
   float* wk = wq + (int64_t)c * 2 * c;            // rows of dk
+  bf16* bq = wdb ? wdb + (int64_t)z * 2 * c * 2 * c : nullptr;
+  bf16* bk = wdb ? bq + (int64_t)c * 2 * c : nullptr;
+  const bool vec = (c & 3) == 0;                  // 4 consecutive rows of a lane: one vector store into the transposed blocks
 #pragma unroll
-  for (int a = 0; a < CT; ++a) {
-    const int i = ti + 16 * a;
+  for (int mb = 0; mb < MB; ++mb) {
+    const int mt = wv + 4 * mb;
+    if (mt >= CT) continue;
+    const int i0 = 16 * mt + 4 * kq;
+    float nq[4];
 #pragma unroll
-    for (int q = 0; q < CT; ++q) {
-      const int j = tj + 16 * q;
-      if (i >= c || j >= c) continue;
-      const float nq = nz[i], nk = nz[c + j];
-      const float g1 = temp * acc[a][q] / (nq * nk);
-      wq[i * 2 * c + j] = g1;            // dq_i += g1 * k_j
-      wk[j * 2 * c + c + i] = g1;        // dk_j += g1 * q_i
-      // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
-      const float nki = nz[c + i];
-      const float dq_ = (i == j) ? ((nq > NORM_EPS) ? -rqs[i] / (nq * nq) : 0.f) : 0.f;
-      const float dk_ = (i == j) ? ((nki > NORM_EPS) ? -rks[i] / (nki * nki) : 0.f) : 0.f;
-      wq[i * 2 * c + c + j] = dq_;
-      wk[i * 2 * c + j] = dk_;
-      if (wdb) {                         // the same matrix in bf16 for the q / k gradient GEMM (mi_pw_desc.w_b16)
-        bf16* bq = wdb + (int64_t)z * 2 * c * 2 * c;
-        bf16* bk = bq + (int64_t)c * 2 * c;
-        bq[i * 2 * c + j] = (bf16)g1; bk[j * 2 * c + c + i] = (bf16)g1;
-        bq[i * 2 * c + c + j] = (bf16)dq_; bk[i * 2 * c + j] = (bf16)dk_;
+    for (int r = 0; r < 4; ++r) nq[r] = i0 + r < c ? nz[i0 + r] : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+      const int j = 16 * nt + li;
+      if (j >= c) continue;
+      const float nk = nz[c + j];
+      float g1[4], dq_[4], dk_[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + r;
+        g1[r] = temp * acc[mb][nt][r] / (nq[r] * nk);
+        // diagonal blocks: projection terms of d(x/|x|); zero when the norm was clamped
+        const bool dg = i == j;
+        dq_[r] = (dg && nq[r] > NORM_EPS) ? -rq[mb][r] / (nq[r] * nq[r]) : 0.f;
+        dk_[r] = (dg && nk > NORM_EPS) ? -rks[j] / (nk * nk) : 0.f;
+        if (i < c) {
+          wq[i * 2 * c + j] = g1[r];            // dq_i += g1 * k_j
+          wq[i * 2 * c + c + j] = dq_[r];
+          wk[i * 2 * c + j] = dk_[r];
+          if (bq) { bq[i * 2 * c + j] = (bf16)g1[r]; bq[i * 2 * c + c + j] = (bf16)dq_[r]; bk[i * 2 * c + j] = (bf16)dk_[r]; }
+        }
+      }
+      // dk_j += g1 * q_i: the transposed block, 4 consecutive i per lane
+      if (vec && i0 + 3 < c) {
+        *reinterpret_cast<f32x4*>(wk + j * 2 * c + c + i0) = (f32x4){g1[0], g1[1], g1[2], g1[3]};
+        if (bk) *reinterpret_cast<u32x2*>(bk + j * 2 * c + c + i0) = (u32x2){cvt_pk_bf16(g1[0], g1[1]), cvt_pk_bf16(g1[2], g1[3])};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i0 + r < c) {
+            wk[j * 2 * c + c + i0 + r] = g1[r];
+            if (bk) bk[j * 2 * c + c + i0 + r] = (bf16)g1[r];
+          }
       }
     }
   }
@@ -460,8 +458,8 @@ int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtyp
   } while (0)
 
 size_t attn_bwd_scratch_floats(int B, int C, int heads) {
-  const size_t c = C / heads;
-  return (size_t)B * heads * attn_rchunks(C) * c * c;
+  (void)B; (void)C; (void)heads;
+  return 64;            // (the one-launch backward keeps dA in registers: nothing to stage; the carve stays for the ABI)
 }
 
 int launch_attn_fold(const float* graw, const float* ss, const float* temperature, const float* wo, float* P, float* A,
@@ -487,24 +485,20 @@ int launch_attn_fold(const float* graw, const float* ss, const float* temperatur
   return MI_OK;
 }
 
-// scratch: attn_bwd_scratch_floats() floats for the per-chunk dA partials
 int launch_attn_bwd_small(const float* dM, const float* A, const float* P, const float* nrm, const float* temperature,
                           const float* wo, float* dwo_part, float* dtemp_part, float* wd, float* scratch,
                           int B, int C, int heads, hipStream_t st, void* wdb) {
+  (void)scratch;
   const int c = C / heads;
   MI_CHECK_ARG(c >= 1 && c <= ATTN_MAX_C && c * heads == C, "mdta: channels per head %d unsupported (1..%d)", c, ATTN_MAX_C);
-  MI_CHECK_ARG(scratch, "mdta: null attention scratch");
-  const int ld = attn_ld(c), rch = attn_rchunks(C);
-  const size_t lds = ((size_t)c * ld + 2 * ATT_RC * c) * sizeof(float);
+  MI_CHECK_ARG(dM && A && P && nrm && temperature && wo && dwo_part && dtemp_part && wd, "mdta: null pointer in the attention backward");
   ProfScope ps(st, K_ATTN_BWD_SMALL, 4.0 * B * (6.0 * C * c + 3.0 * C * C), 4.0 * B * C * (double)c * C);
   ATTN_CT_SWITCH(attn_ct(c), {
+    const size_t lds = attn_bwd_lds_floats(CT) * sizeof(float);
     if (lds > 64 * 1024)
-      MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_partial_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-    hipLaunchKernelGGL((attn_bwd_partial_kernel<CT>), dim3(B * heads, rch), dim3(256), lds, st, dM, A, wo, scratch, dwo_part, C,
-                       heads, ld);
-    hipLaunchKernelGGL((attn_bwd_finish_kernel<CT>), dim3(B * heads), dim3(256), 0, st, (const float*)scratch, rch, A, P, nrm,
-                       temperature, dtemp_part, wd, (bf16*)wdb, C, heads);
+      MI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_bwd_kernel<CT>), dim3(B * heads, 1 + cdiv(C, ATT_RW)), dim3(256), lds, st, dM, A, P, nrm, temperature, wo,
+                       dwo_part, dtemp_part, wd, (bf16*)wdb, C, heads);
   });
   MI_LAUNCH_CHECK();
   return MI_OK;
