@@ -422,6 +422,47 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
+// Few slices (splits x summed images <= 16): one thread per output element, the slices walked in order with all loads in flight
+// (the 16-phase kernel above keeps 1/16 of its lanes busy there: 33 us for 43 MB at C = 384, profiles/r04_f_attn_small.txt).
+template <int NS>
+__global__ __launch_bounds__(256) void gram_reduce_few_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int total, int batch, int groups, int ma, int mb, int64_t out_ld,
+                                                              int64_t out_zs, int sum_batch, int accumulate) {
+  const int64_t per = (int64_t)ma * mb;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int zo = blockIdx.y;
+  if (e >= per) return;
+  const int Z = batch * groups;
+  const int nb = sum_batch ? batch : 1;
+  float v[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const int sp = q / nb, b = q - sp * nb;
+    const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
+    v[q] = q < total ? part[((int64_t)sp * Z + zz) * per + e] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) s += v[q];
+  const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
+  float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
+  *o = (accumulate ? *o : 0.f) + s;
+}
+static void launch_gram_reduce(const float* part, float* out, int splits, int batch, int groups, int ma, int mb, int64_t out_ld,
+                               int64_t out_zs, int sum_batch, int accumulate, int zo, hipStream_t st) {
+  const int64_t per = (int64_t)ma * mb;
+  const int total = splits * (sum_batch ? batch : 1);
+  if (total <= 4)
+    hipLaunchKernelGGL(gram_reduce_few_kernel<4>, dim3(cdiv(per, 256), zo), dim3(256), 0, st, part, out, total, batch, groups, ma, mb,
+                       out_ld, out_zs, sum_batch, accumulate);
+  else if (total <= 16)
+    hipLaunchKernelGGL(gram_reduce_few_kernel<16>, dim3(cdiv(per, 256), zo), dim3(256), 0, st, part, out, total, batch, groups, ma, mb,
+                       out_ld, out_zs, sum_batch, accumulate);
+  else
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, part, out, splits, batch, groups, ma, mb, out_ld,
+                       out_zs, sum_batch, accumulate);
+}
+
 // A weight-gradient Gram that accumulates into a dense [ma][mb] gradient may leave its split partials in the deferred arena
 // and have them summed by mi_deferred_flush (common.h): rows = splits x images of ma*mb floats, a plain fixed-order row sum.
 static bool gram_deferrable(const mi_gram_desc* d) {
@@ -596,8 +637,8 @@ static int gram_stream_launch(const mi_gram_desc* d, void* ws, hipStream_t st) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits,
-                       g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    launch_gram_reduce(k.part, d->out, g.splits, g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch,
+                       d->accumulate, zo, st);
     MI_LAUNCH_CHECK();
   }
   if (ss) {
@@ -668,8 +709,8 @@ extern "C" int mi_gram(const mi_gram_desc* d, void* ws, void* stream) {
     ProfScope ps2(st, K_GRAM_REDUCE, 4.0 * (g.splits + 1) * g.Z * d->ma * d->mb, (double)g.splits * g.Z * d->ma * d->mb);
     const int zo = d->sum_batch ? d->groups : g.Z;
     const int64_t per = (int64_t)d->ma * d->mb;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(per, 16), zo), dim3(256), 0, st, k.part, d->out, g.splits,
-                       g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch, d->accumulate);
+    launch_gram_reduce(k.part, d->out, g.splits, g.fold ? 1 : d->batch, d->groups, d->ma, d->mb, d->out_ld, d->out_zs, d->sum_batch,
+                       d->accumulate, zo, st);
     MI_LAUNCH_CHECK();
   }
   if (ss) {
