@@ -136,7 +136,6 @@ struct DrJob {
   int blk1, blk2;                 // first workgroup of this job within its generation's launch / its generation
 };
 constexpr int DR_MAX_JOBS = 2048;
-constexpr int DR_COLS = 32;      // columns of a job per workgroup of the flush kernel
 constexpr size_t DR_TABLE_BYTES = DR_MAX_JOBS * sizeof(DrJob);
 static struct {
   std::mutex mu;
@@ -202,19 +201,16 @@ bool deferred_reduce_rows(const float* part, float* out, int64_t rows, int64_t c
   if ((int)g_dr.gen_blocks.size() <= gen) g_dr.gen_blocks.resize(gen + 1, 0);
   j.blk2 = gen;
   j.blk1 = g_dr.gen_blocks[gen];
-  g_dr.gen_blocks[gen] += (int)cdiv(cols, DR_COLS);
-  g_dr.nblk1 += (int)cdiv(cols, DR_COLS);
+  g_dr.gen_blocks[gen] += (int)cdiv(cols, 256);
+  g_dr.nblk1 += (int)cdiv(cols, 256);
   g_dr.jobs.push_back(j);
   return true;
 }
 
-// One workgroup = 32 consecutive columns of one job x 8 row phases: thread (cx, ph) walks rows ph, ph + 8, ... with eight loads
-// in flight (eight partial sums combined in a fixed pattern), the phases are combined through LDS in a fixed order: reproducible.
-// (One column per thread over ALL rows - the first form - left the whole launch waiting for the longest job: the depthwise
-// partials have thousands of rows, 540 us per flush at bs 32.)  128-byte row segments; the job is found by a binary search
-// over the jobs' first-workgroup indices.
+// One workgroup = 256 consecutive columns of one job, one column per thread, the rows walked in order with eight loads in
+// flight (eight partial sums combined in a fixed pattern: reproducible).  Coalesced 1-KiB row segments; the job is found by a
+// binary search over the jobs' first-workgroup indices.
 __global__ __launch_bounds__(256) void deferred_reduce_kernel(const DrJob* __restrict__ jobs, int njobs) {
-  __shared__ float sm[8][DR_COLS + 1];
   const int bid = blockIdx.x;
   int lo = 0, hi = njobs - 1;                            // the last job whose first workgroup is <= bid
   while (lo < hi) {
@@ -222,29 +218,19 @@ __global__ __launch_bounds__(256) void deferred_reduce_kernel(const DrJob* __res
     if (jobs[mid].blk1 <= bid) lo = mid; else hi = mid - 1;
   }
   const DrJob j = jobs[lo];
-  const int cx = threadIdx.x & (DR_COLS - 1), ph = threadIdx.x / DR_COLS;
-  const int64_t c = (int64_t)(bid - j.blk1) * DR_COLS + cx;
-  float t = 0.f;
-  if (c < j.cols) {
-    const float* p = j.part + c;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int64_t r = ph;
-    for (; r + 56 < j.rows; r += 64) {
+  const int64_t c = (int64_t)(bid - j.blk1) * 256 + threadIdx.x;
+  if (c >= j.cols) return;
+  const float* p = j.part + c;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int64_t r = 0;
+  for (; r + 7 < j.rows; r += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += p[(r + 8 * u) * j.ld];
-    }
-    for (; r < j.rows; r += 8) a[0] += p[r * j.ld];
-    t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int u = 0; u < 8; ++u) a[u] += p[(r + u) * j.ld];
   }
-  sm[ph][cx] = t;
-  __syncthreads();
-  if (ph == 0 && c < j.cols) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += sm[k][cx];
-    float* o = (j.out2 && c >= j.split) ? j.out2 + (c - j.split) : j.out + c;
-    *o = (j.accumulate ? *o : 0.f) + j.scale * s;
-  }
+  for (; r < j.rows; ++r) a[0] += p[r * j.ld];
+  const float t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  float* o = (j.out2 && c >= j.split) ? j.out2 + (c - j.split) : j.out + c;
+  *o = (j.accumulate ? *o : 0.f) + j.scale * t;
 }
 
 // AdamW, torch semantics (decoupled weight decay, bias-corrected moments).

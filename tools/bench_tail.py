@@ -7,6 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import image_restoration_amd as m  # noqa: E402
 from image_restoration_amd import ops  # noqa: E402
 
 DEV = "cuda"
@@ -67,8 +68,10 @@ def main():
                 flags = tuple((int(f), "dbg " + f) for f in os.environ["BT_ABLATE"].split(","))
             for flag, what in flags:
                 os.environ["MI_BT_DEBUG"] = str(flag)
+                m.reload_env()
                 print(f"      {what:14s} {timeit(tail):8.1f} us", flush=True)
             os.environ["MI_BT_DEBUG"] = "0"
+            m.reload_env()
 
 
 if __name__ == "__main__":
