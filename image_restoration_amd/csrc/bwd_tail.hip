@@ -408,35 +408,44 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
   }
 }
 
-// [G | S] (already summed over workgroups; row stride C + 1) -> dW = gamma G + beta S, dgamma = colsum(W o G), dbeta = W^T S.
-// One block of 1024 threads per 32 columns: 32 row phases, so a thread walks M / 32 rows (with 8 phases the dependent
-// read-modify-write of dW made this 27 us per launch).
-__global__ __launch_bounds__(1024) void bt_finish_kernel(const float* __restrict__ GS, const float* __restrict__ w,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ dw, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int M, int C, int accumulate) {
-  __shared__ float sg[32][33], sb[32][33];
-  const int cx = threadIdx.x & 31, ph = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
-  float ag = 0.f, ab = 0.f;
-  if (c < C) {
-    const float gc = gamma[c], bc = beta ? beta[c] : 0.f;
-    for (int m = ph; m < M; m += 32) {
-      const float gg = GS[(int64_t)m * (C + 1) + c], ss = GS[(int64_t)m * (C + 1) + C], ww = w[(int64_t)m * C + c];
-      float* o = dw + (int64_t)m * C + c;
-      *o = (accumulate ? *o : 0.f) + gc * gg + bc * ss;
-      ag += ww * gg;
-      ab += ww * ss;
-    }
-  }
-  sg[ph][cx] = ag;
-  sb[ph][cx] = ab;
-  __syncthreads();
-  if (ph == 0 && c < C) {
-    float tg = 0.f, tb = 0.f;
+// The per-workgroup partials [nparts][M][C + 1] -> dW = gamma G + beta S (into dw, accumulating or not) and, per row m, the
+// contributions W[m,c] G[m,c] | W[m,c] S[m] to dgamma | dbeta (gb[M][2C]; a row sum - deferred when the caller's step records
+// deferred sums - finishes them).  One workgroup per row m: 128 column slots x 8 phases over the partial copies, eight loads in
+// flight per thread.  Replaces the two-stage row sum (49 k workgroups of one load per thread at M = 510) + bt_finish_kernel:
+// 48 -> 16 us behind the largest tail (profiles/r04_g_bwd_tail_ablation.txt).
+__global__ __launch_bounds__(1024) void bt_finish2_kernel(const float* __restrict__ gpart, int nparts, const float* __restrict__ w,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ dw, float* __restrict__ gb, int M, int C, int accumulate) {
+  __shared__ float sm[8][128];
+  const int m = blockIdx.x, cx = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  const int64_t mc = (int64_t)M * (C + 1);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cx <= C) {
+    const float* p = gpart + (int64_t)m * (C + 1) + cx;
+    int r = ph;
+    for (; r + 56 < nparts; r += 64) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { tg += sg[k][cx]; tb += sb[k][cx]; }
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + tg;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + tb;
+      for (int u = 0; u < 8; ++u) a[u] += p[(int64_t)(r + 8 * u) * mc];
+    }
+    for (; r < nparts; r += 8) a[0] += p[(int64_t)r * mc];
+  }
+  sm[ph][cx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  float t = 0.f;
+  if (ph == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][cx];
+  }
+  __syncthreads();
+  if (ph == 0) sm[0][cx] = t;
+  __syncthreads();
+  if (ph == 0 && cx < C) {
+    const float gg = sm[0][cx], ss = sm[0][C];
+    float* o = dw + (int64_t)m * C + cx;
+    *o = (accumulate ? *o : 0.f) + gamma[cx] * gg + (beta ? beta[cx] * ss : 0.f);
+    const float ww = w[(int64_t)m * C + cx];
+    gb[(int64_t)m * 2 * C + cx] = ww * gg;
+    gb[(int64_t)m * 2 * C + C + cx] = ww * ss;
   }
 }
 
@@ -522,13 +531,18 @@ int launch_bwd_tail(const void* dy, int M, const void* x, int C, const void* dre
     else if (p.MPW == 4) MI_TRY((bt_launch<48, 4, 4>(a, grid, st)));
     else MI_TRY((bt_launch<48, 4, 3>(a, grid, st)));
   }
-  MI_TRY(launch_reduce_rows(gpart, gsum, grid, (int64_t)mc, (int64_t)mc, 0, 1.0f, st, tmp));
+  // partials -> dW and the per-row dgamma | dbeta contributions; their row sum is a parameter-gradient sum like any other
+  // (deferred into the step's flush when the caller records, launched here otherwise)
+  (void)gsum;
+  float* gb = accumulate ? deferred_take((size_t)M * 2 * C, st) : nullptr;
+  if (!gb) gb = tmp;
   {
-    ProfScope ps(st, K_BWD_TAIL_FIN, 4.0 * mc * 4, 4.0 * mc);
-    hipLaunchKernelGGL(bt_finish_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, gsum, w, gamma, beta, dw, dgamma, dbeta, M, C,
-                       accumulate);
+    ProfScope ps(st, K_BWD_TAIL_FIN, 4.0 * (grid + 2.0) * mc, (double)grid * mc);
+    hipLaunchKernelGGL(bt_finish2_kernel, dim3(M), dim3(1024), 0, st, gpart, grid, w, gamma, beta, dw, gb, M, C, accumulate);
     MI_LAUNCH_CHECK();
   }
+  if (dbeta) MI_TRY(launch_reduce_rows(gb, dgamma, M, 2 * C, 2 * C, accumulate, 1.0f, st, nullptr, dbeta, C));
+  else MI_TRY(launch_reduce_rows(gb, dgamma, M, C, 2 * C, accumulate, 1.0f, st, nullptr, nullptr, 0));
   return MI_OK;
 }
 
