@@ -391,6 +391,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 // per-channel sum over batch and pixels:  part[split][c] = sum x[b][c][n-range]
+// The (image, vector) items of a workgroup form one index space walked with four loads in flight per thread: as a loop over the
+// images with one dependent load each this kernel took an HBM round trip per image (19 us per call at bs 8 on MoCE-IR's planes).
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, float* __restrict__ part, int B, int C,
                                                        int64_t N, int64_t per_split) {
@@ -404,16 +406,31 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, 
   // (vec: whole 16-byte vectors - N, the split bounds and the base pointer allow it; a 2-byte load per lane made this kernel
   //  instruction-bound: 34 us per call on MoCE-IR's planes, 7 % of its step)
   const bool vec = (N % V == 0) && (nb % V == 0) && (ne % V == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  for (int b = 0; b < B; ++b) {
-    const T* row = x + ((int64_t)b * C + c) * N;
-    if (vec) {
-      for (int64_t n = nb + (int64_t)threadIdx.x * V; n < ne; n += 256 * V) {
-        float v[V];
-        Vec<T, V>::ld(row + n, v);
+  if (vec && ne > nb) {
+    const int64_t nvec = (ne - nb) / V, items = (int64_t)B * nvec;
+    const T* base = x + (int64_t)c * N + nb;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i0 = threadIdx.x; i0 < items; i0 += 4 * 256) {
+      float v[4][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc += v[j];
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + 256 * u;
+        const int64_t b = i / nvec, k = i - b * nvec;
+        if (i < items) Vec<T, V>::ld(base + b * C * N + k * V, v[u]);
+        else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[u][j] = 0.f;
+        }
       }
-    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < V; ++j) a4[u] += v[u][j];
+    }
+    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  } else {
+    for (int b = 0; b < B; ++b) {
+      const T* row = x + ((int64_t)b * C + c) * N;
       for (int64_t n = nb + threadIdx.x; n < ne; n += 256) acc += ld1(row + n);
     }
   }
@@ -437,6 +454,10 @@ int launch_chan_sum(const void* x, float* out, int B, int C, int64_t N, int dtyp
   int64_t per = (N + splits - 1) / splits;
   per = (per + 7) / 8 * 8;                              // split bounds on 16-byte vectors (the last split takes the remainder)
   float* part = (float*)ws;
+  if (accumulate) {          // a parameter gradient accumulated in place: the split sum may wait for mi_deferred_flush (common.h)
+    float* arena = deferred_take((size_t)splits * C, st);
+    if (arena) part = arena;
+  }
   dim3 grid(C, splits), block(256);
   ProfScope ps(st, K_CHAN_SUM, (double)B * C * N * dtype_size(dtype), (double)B * C * N);
   if (dtype == MI_F32) hipLaunchKernelGGL((chan_sum_kernel<float>), grid, block, 0, st, (const float*)x, part, B, C, N, per);

@@ -234,32 +234,44 @@ __global__ __launch_bounds__(256) void route_bwd_kernel(RouteBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------ patch circular convolution
 // out[u][v] = sum_{a,b} x[a][b] * y[(u-a) mod P][(v-b) mod P]  per P x P patch of every (image, channel) plane.
-// One workgroup = one band of P rows x up to 256 columns of one plane: both operand bands are staged in LDS as fp32, a thread
-// owns one output row of one patch (P accumulators); for every row a of x it holds the matching row of y in registers and
-// walks b with statically rotated indices - P*P FMAs per (a) against P+1 LDS reads.
+// One workgroup = one band of P rows x 256 columns: of one plane, or - when the plane is narrower (W < 256, 256 % W == 0,
+// W % P == 0: every training plane of MoCE-IR) - of 256 / W consecutive planes side by side, so that no thread idles on a 128-
+// or 64-pixel row (the first form kept half / three quarters of the workgroup idle there: 60 us per launch on average at
+// bs 8 x 128^2).  Both operand bands are staged in LDS as fp32 (rows 16-byte aligned: the P-float row pieces are read as
+// vectors - with an odd stride the scalar reads of threads 8 floats apart were 8-way bank conflicts); a thread owns one output
+// row of one patch (P accumulators); for every row a of x it holds the matching rows of x and y in registers and walks b with
+// statically rotated indices.
 template <typename T, int P>
 __global__ __launch_bounds__(256) void circconv_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out,
-                                                       int C, int H, int W, int flip, int64_t x_bs, int64_t y_bs, int64_t o_bs) {
+                                                       int C, int H, int W, int flip, int64_t x_bs, int64_t y_bs, int64_t o_bs,
+                                                       int64_t planes, int ppw) {
   constexpr int PPB = 256 / P;                // patches per workgroup
-  constexpr int LS = 256 + 1;                 // LDS row stride (floats)
-  extern __shared__ float csm[];
+  constexpr int LS = 256 + 4;                 // LDS row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) float csm[];
   float* xs = csm;                            // [P][LS]
   float* ys = csm + P * LS;
   const int t = threadIdx.x;
-  const int64_t plane = blockIdx.z;
-  const int r0 = blockIdx.y * P, c0 = blockIdx.x * 256;
-  const int64_t pb = plane / C, pc_ = plane - pb * C;
-  const T* xp = x + pb * x_bs + pc_ * (int64_t)H * W;
-  const T* yp = y + pb * y_bs + pc_ * (int64_t)H * W;
+  const int r0 = blockIdx.y * P;
+  const int c0 = ppw > 1 ? 0 : blockIdx.x * 256;
+  const int64_t plane0 = (int64_t)blockIdx.z * ppw;
+  auto plane_of = [&](int c, int* X) -> int64_t {           // virtual column -> (plane, column)
+    if (ppw > 1) { const int q = c / W; *X = c - q * W; return plane0 + q; }
+    *X = c0 + c;
+    return plane0;
+  };
   for (int i = t; i < P * 256; i += 256) {
     const int r = i >> 8, c = i & 255;
-    const int Y = r0 + r, X = c0 + c;
-    const bool in = Y < H && X < W;
-    xs[r * LS + c] = in ? to_f32(xp[(int64_t)Y * W + X]) : 0.f;
+    int X;
+    const int64_t plane = plane_of(c, &X);
+    const int Y = r0 + r;
+    const bool in = Y < H && X < W && plane < planes;
+    const int64_t pb = plane / C, pc_ = plane - pb * C;
+    const int64_t off = pc_ * (int64_t)H * W + (int64_t)Y * W + X;
+    xs[r * LS + c] = in ? to_f32(x[pb * x_bs + off]) : 0.f;
     // flip: y'[i][j] = y[(-i) mod P][(-j) mod P] within each patch (correlation form used by the input gradients)
     int rr = r, cc = c;
     if (flip) { rr = (P - r) % P; cc = (c / P) * P + (P - c % P) % P; }
-    ys[rr * LS + cc] = in ? to_f32(yp[(int64_t)Y * W + X]) : 0.f;
+    ys[rr * LS + cc] = in ? to_f32(y[pb * y_bs + off]) : 0.f;
   }
   __syncthreads();
   const int u = t / PPB, pw = t % PPB;        // consecutive threads -> consecutive patches of one output row: coalesced stores
@@ -269,22 +281,29 @@ __global__ __launch_bounds__(256) void circconv_kernel(const T* __restrict__ x, 
   for (int v = 0; v < P; ++v) acc[v] = 0.f;
   for (int a = 0; a < P; ++a) {
     const int yr = (u - a + P) % P;
-    float kr[P];
+    float kr[P], qr[P];
 #pragma unroll
-    for (int v = 0; v < P; ++v) kr[v] = ys[yr * LS + pc + v];
+    for (int v = 0; v < P; v += 4) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(&ys[yr * LS + pc + v]);
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(&xs[a * LS + pc + v]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kr[v + e] = k4[e]; qr[v + e] = q4[e]; }
+    }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      const float q = xs[a * LS + pc + b];
 #pragma unroll
-      for (int v = 0; v < P; ++v) acc[v] += q * kr[(v - b + P) % P];
+      for (int v = 0; v < P; ++v) acc[v] += qr[b] * kr[(v - b + P) % P];
     }
   }
   const int Y = r0 + u;
-  if (Y < H) {
+  int X0;
+  const int64_t plane = plane_of(pc, &X0);
+  if (Y < H && plane < planes) {
+    const int64_t pb = plane / C, pc_ = plane - pb * C;
     T* op = out + pb * o_bs + pc_ * (int64_t)H * W + (int64_t)Y * W;
 #pragma unroll
     for (int v = 0; v < P; ++v)
-      if (c0 + pc + v < W) op[c0 + pc + v] = Cvt<T>::from(acc[v]);
+      if (X0 + v < W) op[X0 + v] = Cvt<T>::from(acc[v]);
   }
 }
 
@@ -292,13 +311,15 @@ template <typename T>
 static int circconv_launch(const void* x, const void* y, void* out, int B, int C, int H, int W, int p, int flip, int64_t x_bs,
                            int64_t y_bs, int64_t o_bs, hipStream_t st) {
   const int64_t planes = (int64_t)B * C;
-  dim3 grid((unsigned)cdiv(W, 256), (unsigned)cdiv(H, p), (unsigned)planes);
-  MI_CHECK_ARG(planes < 65536 * 32 && grid.y < 65536, "patch_circconv: grid too large");
-  const size_t lds = 2 * (size_t)p * 257 * sizeof(float);
+  const int ppw = (W < 256 && 256 % W == 0 && W % p == 0) ? 256 / W : 1;    // planes side by side in one workgroup
+  dim3 grid(ppw > 1 ? 1u : (unsigned)cdiv(W, 256), (unsigned)cdiv(H, p), (unsigned)cdiv(planes, ppw));
+  MI_CHECK_ARG(planes < 65536 * 32 && grid.y < 65536 && grid.z < 65536 * 32, "patch_circconv: grid too large");
+  const size_t lds = 2 * (size_t)p * 260 * sizeof(float);
 #define CC(PP)                                                                                                             \
   case PP:                                                                                                                 \
     if (lds > 64 * 1024) MI_CHECK_HIP(hipFuncSetAttribute((const void*)circconv_kernel<T, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((circconv_kernel<T, PP>), grid, dim3(256), lds, st, (const T*)x, (const T*)y, (T*)out, C, H, W, flip, x_bs, y_bs, o_bs); \
+    hipLaunchKernelGGL((circconv_kernel<T, PP>), grid, dim3(256), lds, st, (const T*)x, (const T*)y, (T*)out, C, H, W, flip, x_bs, y_bs, o_bs, \
+                       planes, ppw);                                                                                       \
     break
   switch (p) { CC(4); CC(8); CC(16); CC(32); default: set_error("patch_circconv: patch size %d not in {4,8,16,32}", p); return MI_ERR_ARG; }
 #undef CC
