@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fold_kernel(const float* __restrict_
     mx = row16_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < CT; ++q) { sv[q] = __expf(sv[q] - mx); sum += sv[q]; }
+    for (int q = 0; q < CT; ++q) { sv[q] = expf(sv[q] - mx); sum += sv[q]; }
     sum = row16_sum(sum);
     const float inv = 1.0f / sum;
 #pragma unroll

@@ -259,19 +259,27 @@ __global__ __launch_bounds__(256) void circconv_kernel(const T* __restrict__ x, 
     *X = c0 + c;
     return plane0;
   };
-  for (int i = t; i < P * 256; i += 256) {
-    const int r = i >> 8, c = i & 255;
+  {                                           // thread t stages virtual column t of every row of the band
     int X;
-    const int64_t plane = plane_of(c, &X);
-    const int Y = r0 + r;
-    const bool in = Y < H && X < W && plane < planes;
+    const int64_t plane = plane_of(t, &X);
     const int64_t pb = plane / C, pc_ = plane - pb * C;
-    const int64_t off = pc_ * (int64_t)H * W + (int64_t)Y * W + X;
-    xs[r * LS + c] = in ? to_f32(x[pb * x_bs + off]) : 0.f;
+    const bool cin = X < W && plane < planes;
+    const T* xq = x + pb * x_bs + pc_ * (int64_t)H * W + X;
+    const T* yq = y + pb * y_bs + pc_ * (int64_t)H * W + X;
     // flip: y'[i][j] = y[(-i) mod P][(-j) mod P] within each patch (correlation form used by the input gradients)
-    int rr = r, cc = c;
-    if (flip) { rr = (P - r) % P; cc = (c / P) * P + (P - c % P) % P; }
-    ys[rr * LS + cc] = in ? to_f32(y[pb * y_bs + off]) : 0.f;
+    const int cc = flip ? (t / P) * P + (P - t % P) % P : t;
+    float xv[P], yv[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      const bool in = cin && r0 + r < H;
+      xv[r] = in ? to_f32(xq[(int64_t)(r0 + r) * W]) : 0.f;
+      yv[r] = in ? to_f32(yq[(int64_t)(r0 + r) * W]) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      xs[r * LS + t] = xv[r];
+      ys[(flip ? (P - r) % P : r) * LS + cc] = yv[r];
+    }
   }
   __syncthreads();
   const int u = t / PPB, pw = t % PPB;        // consecutive threads -> consecutive patches of one output row: coalesced stores

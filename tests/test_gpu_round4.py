@@ -257,3 +257,32 @@ def test_forward_gelu_of_the_bf16_kernels_stays_within_its_stated_bound():
     u = x * (-2.3083120 - 0.1004116 * x * x)
     fast = x / (1 + torch.exp2(u))
     assert float((fast - exact).abs().max()) < 3.0e-4
+
+
+@pytest.mark.parametrize("c,heads,shape", [(40, 1, (2, 40, 8, 16)), (72, 3, (2, 72, 8, 16)), (30, 3, (1, 30, 16, 8)),
+                                           (112, 1, (1, 112, 8, 16)), (120, 1, (2, 120, 8, 8)), (128, 2, (1, 128, 8, 8)),
+                                           (384, 8, (3, 384, 4, 8))])
+def test_attention_small_kernels_at_padded_and_wide_heads(c, heads, shape):
+    """The c x c side of MDTA (attn_fold: DPP-row softmax + fp32-MFMA fold; the one-launch attention backward) pads channels per
+    head to a multiple of 16 in LDS and masks at the stores: channels per head that are NOT multiples of 16 (40, 24, 10), the
+    widest tiles (112, 120 -> 8 x 8 fragments), C not a multiple of 4 (scalar path of the transposed stores) and several W_o row
+    chunks per workgroup (384 / 8 heads at 3 images) against the fp64 oracle (Restormer.py:111-131), forward, dx and every
+    parameter gradient, bound 5e-5."""
+    import image_restoration_amd as m
+    from oracle import restormer_ref as R
+    from oracle.fixtures import seeded_input
+    sd = R.make_block_state(c, heads, 2.66, True, "WithBias", seed=3 * c + heads)
+    blk = m.TransformerBlock(c, heads, 2.66, True, "WithBias").to("cuda")
+    blk.load_state_dict(sd)
+    x, cot = seeded_input(shape, 4100 + c), seeded_input(shape, 4101 + c)
+    xg = x.to("cuda").requires_grad_(True)
+    y = blk(xg)
+    y.backward(cot.to("cuda"))
+    xr = x.double().requires_grad_(True)
+    sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    yr = R.transformer_block(xr, sdr, heads, "WithBias")
+    yr.backward(cot.double())
+    assert rel(y, yr) < 5e-5
+    assert rel(xg.grad, xr.grad) < 5e-5
+    for k, p in blk.named_parameters():
+        assert rel(p.grad, sdr[k].grad) < 5e-5, k
