@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   }
 }
 
-// Few slices (splits x summed images <= 16): one thread per output element, the slices walked in order with all loads in flight
+// Few slices, or enough output elements to fill the chip: one thread per output element, the slices walked in order NS at a time
 // (the 16-phase kernel above keeps 1/16 of its lanes busy there: 33 us for 43 MB at C = 384, profiles/r04_f_attn_small.txt).
 template <int NS>
 __global__ __launch_bounds__(256) void gram_reduce_few_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -434,16 +434,19 @@ __global__ __launch_bounds__(256) void gram_reduce_few_kernel(const float* __res
   if (e >= per) return;
   const int Z = batch * groups;
   const int nb = sum_batch ? batch : 1;
-  float v[NS];
-#pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    const int sp = q / nb, b = q - sp * nb;
-    const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
-    v[q] = q < total ? part[((int64_t)sp * Z + zz) * per + e] : 0.f;
-  }
   float s = 0.f;
+  for (int q0 = 0; q0 < total; q0 += NS) {       // NS loads in flight, summed in slice order
+    float v[NS];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) s += v[q];
+    for (int u = 0; u < NS; ++u) {
+      const int q = q0 + u;
+      const int sp = q / nb, b = q - sp * nb;
+      const int64_t zz = sum_batch ? ((int64_t)b * groups + zo) : zo;
+      v[u] = q < total ? part[((int64_t)sp * Z + zz) * per + e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) s += v[u];
+  }
   const int i = (int)(e / mb), j = (int)(e - (int64_t)i * mb);
   float* o = out + (int64_t)zo * out_zs + (int64_t)i * out_ld + j;
   *o = (accumulate ? *o : 0.f) + s;
@@ -455,7 +458,7 @@ static void launch_gram_reduce(const float* part, float* out, int splits, int ba
   if (total <= 4)
     hipLaunchKernelGGL(gram_reduce_few_kernel<4>, dim3(cdiv(per, 256), zo), dim3(256), 0, st, part, out, total, batch, groups, ma, mb,
                        out_ld, out_zs, sum_batch, accumulate);
-  else if (total <= 16)
+  else if (total <= 16 || per * zo >= 16384)      // enough elements to fill the chip with one thread each: slices walked in the thread
     hipLaunchKernelGGL(gram_reduce_few_kernel<16>, dim3(cdiv(per, 256), zo), dim3(256), 0, st, part, out, total, batch, groups, ma, mb,
                        out_ld, out_zs, sum_batch, accumulate);
   else

@@ -121,8 +121,10 @@ class FlatTrainer:
         # Every weight gradient ends in a fixed-order sum of partial rows; with an arena lent to the library those ~500 small
         # launches per step are recorded during backward and run as one table-driven launch before the gradients are used
         # (reduce_gradients / each bucket's all-reduce).  MI_DEFER_MB sizes the arena (0 disables; overflow falls back to
-        # immediate sums).
-        defer_mb = int(ops.env("MI_DEFER_MB") or 3072)
+        # immediate sums).  Restormer base at bs 32 x 256^2 records 4.8 GB of partial rows per backward (tools/debug_defer_hw.py;
+        # the per-image rows of the weight-gradient Grams are most of it): the 3 GiB of rounds 3-4 overflowed there and the
+        # attention and LayerNorm sums of the early levels, recorded last, fell back to ~120 immediate launches per step.
+        defer_mb = int(ops.env("MI_DEFER_MB") or 6144)
         self._defer_token = ops.deferred_begin(defer_mb << 20, dev) if (dev.type == "cuda" and defer_mb > 0) else None
         self._pack_cache = bool(pack_cache) and dev.type == "cuda"
         self._sync = True            # False inside no_sync(): micro-batches accumulate locally, nothing is reduced
