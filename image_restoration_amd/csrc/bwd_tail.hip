@@ -36,7 +36,10 @@ namespace mi {
 namespace {
 using namespace fz;
 
-constexpr int BT_PS = 72;   // bf16 row stride of every 64-pixel LDS tile (64 + pad: conflict-free 8-byte and transposed reads)
+#ifndef BT_PS_ELEMS
+#define BT_PS_ELEMS 72
+#endif
+constexpr int BT_PS = BT_PS_ELEMS;   // bf16 row stride of every 64-pixel LDS tile (64 + pad: conflict-free 8-byte and transposed reads)
 
 struct BtArgs {
   const bf16* dy;      // [B][M][N]
@@ -320,6 +323,12 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
 
   // Tile loop, software-pipelined across tiles: the LayerNorm phase and the dx store of tile i-1 run inside tile i, between the
   // request for the second half of tile i's dY rows and its first use - the only place where a load had no lead.
+#ifdef BT_STAMP   // variant build (tools/bt_stamps.py): shader-clock time per phase, summed per wave, written in place of [G | S]
+  unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = fm_clock();
+#define BT_TICK(i) { const unsigned long long tn_ = fm_clock(); tk[i] += tn_ - t_prev; t_prev = tn_; }
+#else
+#define BT_TICK(i)
+#endif
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
     if (active) issue_dy(tile, 0);
@@ -337,7 +346,9 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     bf16* const xh_prev = reinterpret_cast<bf16*>(lds + K::OFF_XH + (buf ^ 1) * K::TILE_B);
     bf16* const dr_prev = reinterpret_cast<bf16*>(lds + K::OFF_DR + (buf ^ 1) * K::TILE_B);
     // ---- this wave's DMA pieces and dY half have landed: dY -> patch, x -> xh = (x - mean) rstd in place
+    BT_TICK(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BT_TICK(1);
     if (active) stage_dy(0);
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
@@ -359,23 +370,33 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
       }
     }
     const f32x2 rstd_p = *reinterpret_cast<const f32x2*>(&st[64 + 2 * (t / (2 * LPP))]);   // (this lane's pixel pair) read before the next tile's statistics are requested
+    BT_TICK(2);
     __syncthreads();
+    BT_TICK(3);
     if (active) issue_dy(tile, 1);
     // ---- tile i-1: LayerNorm backward, transpose through its dres tile, store dx
     if (have_prev) ln_phase(xh_prev, dr_prev, rstd_prev);
+    BT_TICK(4);
     __syncthreads();
+    BT_TICK(5);
     if (have_prev) store_phase(dr_prev, pb, pp0);
+    BT_TICK(6);
     if (active && !(a.dbg & 32)) {
       wgrad_half(0, xh);
+      BT_TICK(7);
       stage_dy(1);
       wave_sync();
+      BT_TICK(8);
       if (nxt < a.ntiles) issue_dy(nxt, 0);
       wgrad_half(1, xh);
     }
+    BT_TICK(9);
     __syncthreads();                                                     // every wave's dY rows of this tile are in LDS
+    BT_TICK(10);
     // every wave is past the store of tile i-1 now too: its x / dres buffers can take tile i+1
     if (nxt < a.ntiles) issue_x(nxt, buf ^ 1);
     if (dxn_wave && !(a.dbg & 34)) dxn_tile();
+    BT_TICK(11);
     __syncthreads();                                                     // dxn tile complete; the patches may be overwritten
     have_prev = true; pb = b; pp0 = p0; rstd_prev = rstd_p;
   }
@@ -387,6 +408,14 @@ __global__ __launch_bounds__(64 * NW, (BtCfg<C, NW, MPW>::BYTES <= 80 * 1024 ? 2
     __syncthreads();
     store_phase(dr_l, pb, pp0);
   }
+#ifdef BT_STAMP
+  if (lane == 0) {
+    float* const gp = a.gpart + (int64_t)blockIdx.x * a.M * (C + 1) + wv * 16;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gp[i] = (float)tk[i];
+  }
+  return;
+#endif
   // ---- this workgroup's partial [G | S]: one [M][C + 1] matrix, the row sums in column C
   if (active) {
     float* const gp = a.gpart + (int64_t)blockIdx.x * a.M * (C + 1);

@@ -27,6 +27,18 @@ __device__ __forceinline__ void lds_wait(s16x4& a, s16x4& b, s16x4& c, s16x4& d,
 __device__ __forceinline__ void lds_wait(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
 }
+// f(integral_constant<int, I>) for I = 0 .. N-1, unrolled at compile time (register arrays indexed by I stay in registers)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// wait for four transposed reads with up to KEEP YOUNGER LDS reads left in flight (LDS operations of a wave complete in issue order)
+template <int KEEP> __device__ __forceinline__ void lds_wait_keep(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+  static_assert(KEEP >= 0 && KEEP <= 15, "lgkmcnt field");
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(KEEP) : "memory");
+}
 __device__ __forceinline__ s16x8 cat8(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
 // LDS operations of one wave execute in issue order; this only keeps the compiler from reordering across the point.
