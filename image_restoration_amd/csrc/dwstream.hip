@@ -72,7 +72,24 @@ __device__ __forceinline__ void wgrad_row(const float* x, const float* up, const
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[9] += mid[j + 1];
 }
-template <typename T> __device__ __forceinline__ void store4(T* p, const float* v) { Vec<T, 4>::st(p, v); }
+// Cache policy by row length: rows of >= 128 pixels (LPR >= 32) stream with the non-temporal loads / stores of common.h; the short
+// rows of the deep levels keep the default policy - their whole tensors are 150-330 MB at bs 32, the producer has just left them in
+// the Infinity Cache and the consumer follows at once (per-shape A/B inside the step, profiles/r04_d_nontemporal_ab.txt: e.g.
+// dwconv_fwd C = 576 @64^2 46.7 us with nt against 32.0 without, while C = 144 @256^2 is 434 against 487).
+#define DWS_NT (LPR >= 32)
+template <bool NT, typename V> __device__ __forceinline__ V dws_ld(const V* p) {
+  if constexpr (NT) return MI_STREAM_LD(p);
+  else return *p;
+}
+template <bool NT, typename T> __device__ __forceinline__ void store4(T* p, const float* v) {
+  if constexpr (NT) {
+    Vec<T, 4>::st(p, v);
+  } else if constexpr (std::is_same<T, float>::value) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+    *reinterpret_cast<u32x2*>(p) = (u32x2){cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+  }
+}
 __device__ __forceinline__ void copy6(float* d, const float* s) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) d[i] = s[i];
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
   if (a.bias) { b1 = a.bias[cc]; if (GATE) b2 = a.bias[cc + a.hidden]; }
   const int yend = min(u.y0 + band_rows, a.H);      // rows [y0, yend) are this unit's outputs
   auto ld = [&](const T* base, int y) -> RV {
-    return (u.active && y >= 0 && y <= yend && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
+    return (u.active && y >= 0 && y <= yend && y < a.H) ? dws_ld<DWS_NT>(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   float p0[6], p1[6], p2[6], q0[GATE ? 6 : 1], q1[GATE ? 6 : 1], q2[GATE ? 6 : 1], v[4];
   RV c1[PF], c2[GATE ? PF : 1];
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
       window_row(v, first, last, p2);
       stencil(w1, b1, p0, p1, p2, o1);
       if (!GATE) {
-        if (st) store4(out1 + (int64_t)y * a.W, o1);
+        if (st) store4<DWS_NT>(out1 + (int64_t)y * a.W, o1);
       } else {
         float o2[4], g[4];
         R::expand(c2[i], v);
@@ -167,14 +184,14 @@ __global__ __launch_bounds__(256) void dws_fwd_kernel(DwArgs a, int planes, int 
         window_row(v, first, last, q2);
         stencil(w2, b2, q0, q1, q2, o2);
         if (out1) {
-          if (st) { store4(out1 + (int64_t)y * a.W, o1); store4(out2 + (int64_t)y * a.W, o2); }
+          if (st) { store4<DWS_NT>(out1 + (int64_t)y * a.W, o1); store4<DWS_NT>(out2 + (int64_t)y * a.W, o2); }
           // the gate is evaluated on the values as stored (what backward re-reads)
 #pragma unroll
           for (int j = 0; j < 4; ++j) { o1[j] = to_f32(Cvt<T>::from(o1[j])); o2[j] = to_f32(Cvt<T>::from(o2[j])); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = gelu_fwd<T>(o1[j]) * o2[j];
-        if (st) store4(outg + (int64_t)y * a.W, g);
+        if (st) store4<DWS_NT>(outg + (int64_t)y * a.W, g);
         copy6(q0, q1); copy6(q1, q2);
       }
       copy6(p0, p1); copy6(p1, p2);
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
   for (int i = 0; i < 9; ++i) wf[i] = a.w[(int64_t)cc * 9 + 8 - i];
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? dws_ld<DWS_NT>(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   float p0[6], p1[6], p2[6], v[4], acc[10];
 #pragma unroll
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(256) void dws_bwd_kernel(DwArgs a, const T* __restr
       if (WANT_DX) {
         float o[4];
         stencil(wf, 0.f, p0, p1, p2, o);
-        if (st) store4(outp + (int64_t)y * a.W, o);
+        if (st) store4<DWS_NT>(outp + (int64_t)y * a.W, o);
       }
       float xr[4];
       R::expand(cx[i], xr);                 // zero beyond the band: those rows belong to the next unit
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
   for (int i = 0; i < 9; ++i) { w1[i] = a.w[(int64_t)j * 9 + 8 - i]; w2[i] = a.w[(int64_t)(j + h) * 9 + 8 - i]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? dws_ld<DWS_NT>(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   // one row of (dg, y1, y2) -> window rows of d1 and d2
   auto gate_row = [&](const RV& rdg, const RV& ry1, const RV& ry2, float* r1, float* r2) {
@@ -314,9 +331,9 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_kernel(DwArgs a, const T* __
       if (o1p) {
         float o[4];
         stencil(w1, 0.f, p0, p1, p2, o);
-        if (st) store4(o1p + (int64_t)y * a.W, o);
+        if (st) store4<DWS_NT>(o1p + (int64_t)y * a.W, o);
         stencil(w2, 0.f, q0, q1, q2, o);
-        if (st) store4(o2p + (int64_t)y * a.W, o);
+        if (st) store4<DWS_NT>(o2p + (int64_t)y * a.W, o);
       }
       if (WANT_DW) {
         float xr[4];
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
   if (a.bias) { bias2[0] = a.bias[j]; bias2[1] = a.bias[j + h]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y, int ymax) -> RV {
-    return (u.active && y >= 0 && y <= ymax && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
+    return (u.active && y >= 0 && y <= ymax && y < a.H) ? dws_ld<DWS_NT>(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   f32x2 hA[6], hB[6], hC[6];            // x rows rho-1, rho, rho+1
   f32x2 p0[6], p1[6], p2[6];            // (d1, d2) rows y-1, y, y+1
@@ -483,8 +500,8 @@ __global__ __launch_bounds__(256) void dws_gate_bwd_rc_kernel(DwArgs a, float* _
         stencil2<true>(w, zero2, p0, p1, p2, o);
         if (st) {
           float oa[4] = {o[0][0], o[1][0], o[2][0], o[3][0]}, ob[4] = {o[0][1], o[1][1], o[2][1], o[3][1]};
-          store4(o1p + (int64_t)y * a.W, oa);
-          store4(o2p + (int64_t)y * a.W, ob);
+          store4<DWS_NT>(o1p + (int64_t)y * a.W, oa);
+          store4<DWS_NT>(o2p + (int64_t)y * a.W, ob);
         }
       }
       if (WANT_DW && y < yend) wgrad_row2(&hA[1], p0, p1, p2, acc);    // x row y, own 4 pixels
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(256) void dws_gate_fwd2_kernel(DwArgs a, int planes
   if (a.bias) { bias2[0] = a.bias[cc]; bias2[1] = a.bias[cc + h]; }
   const int yend = min(u.y0 + band_rows, a.H);
   auto ld = [&](const T* base, int y) -> RV {
-    return (u.active && y >= 0 && y <= yend && y < a.H) ? MI_STREAM_LD(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
+    return (u.active && y >= 0 && y <= yend && y < a.H) ? dws_ld<DWS_NT>(reinterpret_cast<const RV*>(base + (int64_t)y * a.W)) : R::zero();
   };
   auto pair_row = [&](const RV& r1, const RV& r2, f32x2* out6) {
     float v1[4], v2[4];
@@ -559,14 +576,14 @@ __global__ __launch_bounds__(256) void dws_gate_fwd2_kernel(DwArgs a, int planes
       stencil2<false>(w, bias2, p0, p1, p2, o);
       float o1[4] = {o[0][0], o[1][0], o[2][0], o[3][0]}, o2[4] = {o[0][1], o[1][1], o[2][1], o[3][1]}, g[4];
       if (out1) {
-        if (st) { store4(out1 + (int64_t)y * a.W, o1); store4(out2 + (int64_t)y * a.W, o2); }
+        if (st) { store4<DWS_NT>(out1 + (int64_t)y * a.W, o1); store4<DWS_NT>(out2 + (int64_t)y * a.W, o2); }
         // the gate is evaluated on the values as stored (what a backward that reads y sees)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o1[q] = to_f32(Cvt<T>::from(o1[q])); o2[q] = to_f32(Cvt<T>::from(o2[q])); }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) g[q] = gelu_fwd<T>(o1[q]) * o2[q];
-      if (st) store4(outg + (int64_t)y * a.W, g);
+      if (st) store4<DWS_NT>(outg + (int64_t)y * a.W, g);
       copy6x2(p0, p1); copy6x2(p1, p2);
     }
   }

@@ -193,6 +193,33 @@ __device__ __forceinline__ void pw_chunk_mma(const T* Xs, const T* Ws, f32x4 (*a
   }
 }
 
+// Default-cache-policy vector accesses for the weight-resident / chunked kernel forms below: they serve the deep levels (C >= 192:
+// tensors of 100-330 MB at bs 32 that the producer has just left in the Infinity Cache and the next kernel reads at once), where the
+// non-temporal policy of Vec<>::ld / ::st measured slower (C = 384 project_in 131 us against 102: profiles/r04_d_nontemporal_ab.txt).
+template <typename T, int V> __device__ __forceinline__ void ld_cached(const T* p, float* o) {
+  if constexpr (std::is_same<T, float>::value) {
+    static_assert(V == 4, "fp32: 16-byte vectors");
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = t[i];
+  } else {
+    static_assert(V == 8, "bf16: 16-byte vectors");
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = bf16_bits_to_f32(t[i] & 0xffffu); o[2 * i + 1] = bf16_bits_to_f32(t[i] >> 16); }
+  }
+}
+template <typename T, int V> __device__ __forceinline__ void st_cached(T* p, const float* v) {
+  if constexpr (std::is_same<T, float>::value) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = cvt_pk_bf16(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+}
+
 // Epilogue: lane holds pixels n0+16nf+4g+{0..3} of output channel m0+mw+16mf+li — 8 bytes per lane scattered over
 // 16 rows.  The rows are staged through LDS (one 16-row fp32 slab per wave at a time, so the only rounding is the final
 // store) and written as whole 128-byte row segments, 16 bytes per lane, with bias and residual added on the way.
@@ -235,11 +262,11 @@ __device__ __forceinline__ void pw_epilogue(const PwK& p, float* lds_f32, const 
         if (p.vec_ok) {
           if (rz) {
             float rr[EPV];
-            Vec<T, EPV>::ld(rz + off, rr);
+            ld_cached<T, EPV>(rz + off, rr);
 #pragma unroll
             for (int j = 0; j < EPV; ++j) o[j] += rr[j];
           }
-          Vec<T, EPV>::st(yz + off, o);
+          st_cached<T, EPV>(yz + off, o);
         } else {
 #pragma unroll
           for (int j = 0; j < EPV; ++j)
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwG q) {
     for (int v = 0; v < XV; ++v) {
       const int64_t nn = n + v * EPVX;
       if (row && p.vec_ok && nn < p.n) {  // vec_ok: n % EPVX == 0 for every row, so the vector is all-in or all-out
-        xreg[v] = MI_STREAM_LD(reinterpret_cast<const u32x4*>(row + nn));
+        xreg[v] = *reinterpret_cast<const u32x4*>(row + nn);
       } else {
         __attribute__((aligned(16))) T tmp[EPVX];
 #pragma unroll
